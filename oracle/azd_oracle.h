@@ -1,0 +1,123 @@
+/*
+ * azd_oracle.h -- C API of the CPU ORACLE.
+ *
+ * TEST INFRASTRUCTURE, NOT PRODUCT CODE.  Only tests/, __graft_entry__.smoke()
+ * and bench.py's cpu_baseline leg may load this library.  The product
+ * (azdopt_amd/, include/azdopt_amd.h) never links, imports or calls it.
+ *
+ * It is a CPU restatement of the reference's data-parallel tree-search path:
+ *   az-discrete-opt/src/nabla/tree/{mod,next_action,empty_transitions,
+ *       graph_operations,state_weight,arc_weight}.rs
+ *   az-discrete-opt/src/nabla/optimizer/mod.rs
+ *   az-discrete-opt/src/nabla/model/{mod,dfdx}.rs
+ *   graph-state/src/rooted_tree/{mod,modify_parent_once,ordered_edge,space}.rs
+ *   graph-state/src/simple_graph/edge.rs
+ *   graph-state/examples/04-c21-tree.rs (driver semantics)
+ *
+ * Pinning status (see DESIGN.md "Oracle"):
+ *   - space layer (edge index, parent modifications, lambda_1, matching):
+ *     pinned by the reference's own unit-test vectors (tests/golden/).
+ *   - tree / optimizer / model layers: the reference holds NO test, fixture or
+ *     golden output for them and cannot be built here (Rust nightly + CUDA
+ *     dfdx, no toolchain, no network)  ==> PARITY UNPINNED by the reference;
+ *     pinned instead by an independent second restatement (oracle/py_oracle.py)
+ *     that must agree bit-for-bit, plus hand-worked micro-cases.
+ */
+#ifndef AZD_ORACLE_H
+#define AZD_ORACLE_H
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct orc_engine orc_engine;
+typedef struct orc_mlp orc_mlp;
+
+/* ---- dimensions (rooted_tree/space.rs:46-48) ---- */
+int orc_state_dim(int n);
+int orc_action_dim(int n);
+int orc_key_words(int n);
+
+/* ---- space-level functions, exposed for the golden-vector tests ---- */
+int orc_edge_colex_position(int u, int v);                 /* edge.rs:48-53  */
+void orc_edge_from_colex_position(int pos, int *mx, int *mn); /* edge.rs:55-65 */
+int orc_action_index(int parent, int child);               /* ordered_edge.rs:35-38 */
+void orc_action_from_index(int index, int *parent, int *child); /* :40-42 */
+/* ordered_edge.rs:52-70; writes (parent, child) pairs, returns count */
+int orc_all_possible_parent_modifications(const uint8_t *parents, int n, int *out_pairs);
+double orc_lambda1_jacobi(const uint8_t *parents, int n);  /* dense symmetric eigen-solve (what faer does) */
+double orc_lambda1_sturm(const uint8_t *parents, int n);   /* tree LDL^T multisection (cost contract) */
+int orc_maximum_matching(const uint8_t *parents, int n, int *out_pairs); /* ordered_edge.rs:94-124 */
+float orc_c21_eval(int n, double lambda1, int matching_size);           /* 04-c21-tree.rs:58-74,98-102 */
+
+/* ---- seeded generators (the reference is unseeded; spec in DESIGN.md) ---- */
+uint64_t orc_key4(uint64_t a, uint64_t b, uint64_t c, uint64_t d);
+void orc_gen_roots(uint64_t seed, uint64_t epoch, uint64_t first_agent, int count, int n,
+                   int kmin, int kmax, uint8_t *parents, uint64_t *permitted);
+void orc_hash_predictions(uint64_t seed, uint64_t first_agent, int count, int action_dim,
+                          uint64_t call, float *out);
+
+/* ---- engine = NablaOptimizer<ROTModifyParentsOnce<N>, M, ActionSet> ---- */
+orc_engine *orc_create(int n, int batch, int threads);
+void orc_destroy(orc_engine *e);
+/* par_new (optimizer/mod.rs:39-118) split around the model call at :72 */
+void orc_new_begin(orc_engine *e, const uint8_t *parents, const uint64_t *permitted);
+void orc_new_end(orc_engine *e, const float *h_theta);
+/* par_roll_out_episodes (:121-191) split around the model call at :175 */
+void orc_rollout_begin(orc_engine *e, const uint32_t *tol, int ntol, uint32_t tol_default);
+int orc_rollout_end(orc_engine *e, const float *h_theta); /* 1 = ArgminImprovement::Improved */
+/* par_update_model (:249-281) without the model call at :279 */
+void orc_observe(orc_engine *e, uint32_t n_obs_tol, float *obs, float *weights);
+/* par_reset_trees (:284-360) split around the model call at :348; the
+ * modify_root closure is applied by the caller, who passes the new roots */
+void orc_reset_begin(orc_engine *e, const uint8_t *parents, const uint64_t *permitted);
+void orc_reset_end(orc_engine *e, const float *h_theta);
+/* the modify_root policy of 04-c21-tree.rs:172-206 with the seeded generator */
+void orc_c21_modify_roots(orc_engine *e, uint64_t seed, uint64_t epoch, uint64_t first_agent,
+                          int kmin, int kmax, uint8_t *parents_out, uint64_t *permitted_out);
+
+const float *orc_state_vecs(orc_engine *e); /* [batch * STATE_DIM] */
+/* counters: see ORC_CTR_* */
+enum {
+    ORC_CTR_EXPANSIONS = 0, /* rollout calls that ended on a new non-terminal node */
+    ORC_CTR_TERMINALS = 1,
+    ORC_CTR_TRANSPOSITIONS = 2,
+    ORC_CTR_VISITED_STEPS = 3,
+    ORC_CTR_SELECT_CALLS = 4,
+    ORC_CTR_SUM_DEG = 5,      /* sum over select calls of out-degree */
+    ORC_CTR_SUM_ACTIONS = 6,  /* sum over select calls of |node.actions| */
+    ORC_CTR_CASCADE_NODES = 7,
+    ORC_CTR_NEW_PREDS = 8,
+    ORC_CTR_ROOT_EXHAUSTED = 9,
+    ORC_CTR_MAX_FRONTIER = 10,
+    ORC_CTR_MAX_DEPTH = 11,
+    ORC_CTR_CURIOSITY_PAIRS = 12,
+    ORC_CTR_COUNT = 16
+};
+void orc_counters(orc_engine *e, uint64_t *out /* [ORC_CTR_COUNT] */);
+void orc_argmin(orc_engine *e, uint8_t *parents, uint64_t *permitted, double *lambda1,
+                int *matching_size, float *eval);
+void orc_tree_sizes(orc_engine *e, int agent, int *n_nodes, int *n_edges, int *n_preds);
+void orc_export_tree(orc_engine *e, int agent, float *c, float *c_star, uint32_t *n_t,
+                     uint32_t *exhausted, uint32_t *act_begin, uint32_t *act_end,
+                     uint64_t *keys /* [n_nodes*KW] */, uint32_t *e_src, uint32_t *e_dst,
+                     uint32_t *e_pp, uint32_t *p_aid, float *p_g, int32_t *p_edge);
+void orc_agent_state(orc_engine *e, int agent, uint8_t *parents, uint64_t *permitted,
+                     uint64_t *path, uint32_t *state_pos, double *lambda1, int *matching_size);
+
+/* ---- evaluator = ActionModel (model/dfdx.rs) as a plain fp32 MLP + Adam ---- */
+/* dims[n_layers+1]; hidden activations ReLU; final_act: 0 none, 1 ReLU, 2 Sigmoid */
+orc_mlp *orc_mlp_create(int n_layers, const int *dims, int final_act, float lr, float beta1,
+                        float beta2, float eps, float l2, uint64_t seed, int threads);
+void orc_mlp_destroy(orc_mlp *m);
+int64_t orc_mlp_num_params(orc_mlp *m);
+void orc_mlp_get_params(orc_mlp *m, float *out); /* per layer: W[out][in] then b[out] */
+void orc_mlp_set_params(orc_mlp *m, const float *in);
+void orc_mlp_forward(orc_mlp *m, int batch, const float *states, float *preds);
+float orc_mlp_update(orc_mlp *m, int batch, const float *states, const float *obs,
+                     const float *weights);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,162 @@
+"""Pins the oracle's space layer against the reference's own unit-test vectors
+(tests/golden/reference_unit_vectors.json) and checks the lambda_1 cost
+contract (tree LDL^T multisection) against dense eigen-solves."""
+import ctypes as C
+import json
+import os
+
+import numpy as np
+import pytest
+
+from oracle import py_oracle as po
+
+GOLD = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "reference_unit_vectors.json")))
+
+
+def _u8(x):
+    return np.asarray(x, np.uint8)
+
+
+def _pv(a):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+def test_edge_colex_bijection(orc):
+    L = orc.lib()
+    n = GOLD["edge_colex_10"]["n_vertices"]
+    i = 0
+    for v in range(n):
+        for u in range(v):
+            assert L.orc_edge_colex_position(v, u) == i
+            mx, mn = C.c_int32(), C.c_int32()
+            L.orc_edge_from_colex_position(i, C.byref(mx), C.byref(mn))
+            assert (mx.value, mn.value) == (v, u)
+            i += 1
+    assert i == 45
+
+
+def test_ordered_edge_index_table(orc):
+    L = orc.lib()
+    for idx, (parent, child) in enumerate(GOLD["ordered_edge_index_first_five"]["parent_child_by_index"]):
+        p, c = C.c_int32(), C.c_int32()
+        L.orc_action_from_index(idx, C.byref(p), C.byref(c))
+        assert (p.value, c.value) == (parent, child)
+        assert L.orc_action_index(parent, child) == idx
+        assert po.edge_from_index(idx) == (parent, child)
+        assert po.edge_index(parent, child) == idx
+
+
+def test_star5_parent_modifications(orc):
+    L = orc.lib()
+    g = GOLD["star5_parent_modifications"]
+    parents = _u8(g["parents"])
+    out = np.zeros(64, np.int32)
+    cnt = L.orc_all_possible_parent_modifications(_pv(parents), 5, _pv(out))
+    got = [[max(out[2 * i], out[2 * i + 1]), min(out[2 * i], out[2 * i + 1])] for i in range(cnt)]
+    assert got == g["expected_edges_max_min"]
+
+
+def test_generator_covers_constrained_trees_on_five(orc):
+    want = sorted(tuple(p) for p in GOLD["constrained_trees_on_five"]["expected_parents"])
+    seen = set()
+    for seed in range(200):
+        parents, _ = orc.gen_roots(seed, 0, 0, 8, 5, 1, 2)
+        for p in parents:
+            seen.add(tuple(int(x) for x in p))
+    assert sorted(seen) == want
+
+
+@pytest.mark.parametrize("name", ["star5_cost", "path5_cost"])
+def test_c21_cost_golden(orc, name):
+    L = orc.lib()
+    g = GOLD[name]
+    parents = _u8(g["parents"])
+    n = len(parents)
+    for f in (L.orc_lambda1_jacobi, L.orc_lambda1_sturm):
+        assert abs(f(_pv(parents), n) - g["lambda_1"]) < g["tolerance"]
+    assert abs(po.lambda1(list(parents), n) - g["lambda_1"]) < g["tolerance"]
+    out = np.zeros(64, np.int32)
+    m = L.orc_maximum_matching(_pv(parents), n, _pv(out))
+    got = sorted(sorted((int(out[2 * i]), int(out[2 * i + 1]))) for i in range(m))
+    key = "possible_matchings" if "possible_matchings" in g else "possible_matchings_sorted"
+    assert got in [sorted(sorted(e) for e in mm) for mm in g[key]]
+    assert po.matching_size(list(parents), n) == m
+
+
+def test_lambda1_contract_vs_dense(orc):
+    """lambda1_sturm == dense eigen-solve to 1e-13 and is bit-identical across the two restatements."""
+    L = orc.lib()
+    rng = np.random.default_rng(0)
+    flips = 0
+    for n in (5, 8, 12, 19, 24):
+        for _ in range(300):
+            parents = np.zeros(n, np.uint8)
+            for v in range(2, n):
+                parents[v] = rng.integers(0, v)
+            a = np.zeros((n, n))
+            for v in range(1, n):
+                a[v, parents[v]] = a[parents[v], v] = 1
+            lam_np = np.linalg.eigvalsh(a)[-1]
+            lam_j = L.orc_lambda1_jacobi(_pv(parents), n)
+            lam_s = L.orc_lambda1_sturm(_pv(parents), n)
+            assert abs(lam_s - lam_np) < 1e-13 * n
+            assert abs(lam_j - lam_np) < 1e-13 * n
+            assert lam_s == po.lambda1([int(x) for x in parents], n)  # bit-identical f64
+            flips += int(np.float32(lam_s) != np.float32(lam_np))
+    assert flips == 0  # f32 rounding agrees with LAPACK on this sample
+
+
+def test_matching_is_maximum(orc):
+    """leaf stripping gives the true matching number (brute force on small trees)."""
+    L = orc.lib()
+    rng = np.random.default_rng(1)
+
+    def brute(n, parents):
+        edges = [(parents[v], v) for v in range(1, n)]
+        best = 0
+        for mask in range(1 << len(edges)):
+            used, ok, k = set(), True, 0
+            for i, (a, b) in enumerate(edges):
+                if mask >> i & 1:
+                    if a in used or b in used:
+                        ok = False
+                        break
+                    used.update((a, b))
+                    k += 1
+            if ok:
+                best = max(best, k)
+        return best
+
+    for _ in range(60):
+        n = int(rng.integers(4, 11))
+        parents = np.zeros(n, np.uint8)
+        for v in range(2, n):
+            parents[v] = rng.integers(0, v)
+        assert L.orc_maximum_matching(_pv(parents), n, None) == brute(n, [int(x) for x in parents])
+        assert po.matching_size([int(x) for x in parents], n) == brute(n, [int(x) for x in parents])
+
+
+def test_eval_squish(orc):
+    L = orc.lib()
+    # 04-c21-tree.rs:58-74: N=19 -> C_UPPER = 5 + 10 = 15, slope 1/13; goal = squish(5.2)
+    assert L.orc_c21_eval(19, 3.2, 2) == np.float32(1.0 / 13.0) * (np.float32(2) + np.float32(3.2) - np.float32(2))
+    assert po.evaluate(19, 3.2, 2) == L.orc_c21_eval(19, 3.2, 2)
+    for n in (5, 10, 17, 19):
+        assert po.evaluate(n, 2.5, 3) == L.orc_c21_eval(n, 2.5, 3)
+
+
+def test_seeded_generators_agree(orc):
+    for n, kmin, kmax in ((5, 1, 2), (8, 2, 10), (19, 5, 76)):
+        parents, permitted = orc.gen_roots(7, 3, 100, 16, n, kmin, kmax)
+        for i in range(16):
+            p, m = po.gen_root(7, 3, 100 + i, n, kmin, kmax)
+            assert p == [int(x) for x in parents[i]]
+            mask = sum(1 << a for a in m)
+            got = sum(int(permitted[i, w]) << (64 * w) for w in range(permitted.shape[1]))
+            assert mask == got
+            assert kmin <= len(m) <= kmax
+            assert all(p[v] < v for v in range(1, n)) and p[n - 1] == 0 and p[1] == 0
+    h = orc.hash_predictions(5, 10, 3, 152, 9)
+    for i in range(3):
+        assert np.array_equal(h[i], po.hash_prediction_row(5, 10 + i, 9, 152))
+    assert h.min() >= 0 and h.max() < 1
