@@ -1,0 +1,128 @@
+"""ctypes loader of libazdopt_amd.so (the C ABI declared in include/azdopt_amd.h).
+
+There is no Python or CPU fallback: if the HIP library is missing or no gfx950
+device is visible, the product fails loudly."""
+import ctypes as C
+import os
+import subprocess
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libazdopt_amd.so")
+_LIB = None
+
+CTR = dict(EXPANSIONS=0, TERMINALS=1, TRANSPOSITIONS=2, VISITED_STEPS=3, SELECT_CALLS=4, SUM_DEG=5,
+           SUM_ACTIONS=6, CASCADE_NODES=7, NEW_PREDS=8, ROOT_EXHAUSTED=9, MAX_FRONTIER=10, MAX_DEPTH=11,
+           CURIOSITY_PAIRS=12, FAILED=15)
+CTR_COUNT = 16
+
+ACT_NONE, ACT_RELU, ACT_SIGMOID = 0, 1, 2
+SPACE_C21 = 1
+
+
+class AzdError(RuntimeError):
+    def __init__(self, status, where):
+        L = lib()
+        msg = L.azd_status_string(status).decode()
+        detail = L.azd_last_error().decode()
+        super().__init__(f"{where}: {msg} (status {status}){': ' + detail if detail else ''}")
+        self.status = status
+
+
+class AdamConfig(C.Structure):  # dfdx AdamConfig as set at 04-c21-tree.rs:87-92
+    _fields_ = [("lr", C.c_float), ("beta1", C.c_float), ("beta2", C.c_float), ("eps", C.c_float), ("l2", C.c_float)]
+
+
+class EngineConfig(C.Structure):
+    _fields_ = [("space_id", C.c_int), ("n", C.c_int), ("batch", C.c_int), ("device", C.c_int),
+                ("node_capacity", C.c_int), ("arc_capacity", C.c_int), ("prediction_capacity", C.c_int),
+                ("first_agent", C.c_uint64)]
+
+
+class Argmin(C.Structure):  # ArgminData<State, Cost>, az-discrete-opt/src/log.rs:1-11
+    _fields_ = [("parents", C.c_uint8 * 32), ("permitted", C.c_uint64 * 4), ("lambda_1", C.c_double),
+                ("matching_size", C.c_int32), ("matching", C.c_int32 * 32), ("eval", C.c_float),
+                ("agent", C.c_int32), ("node", C.c_uint32)]
+
+
+def build(force=False):
+    """Compile the HIP library for gfx950 (cross-compiles without a GPU)."""
+    if force or not os.path.exists(LIB_PATH):
+        subprocess.check_call(["make", "-s", "-j4", "-C", os.path.join(_HERE, "csrc")])
+    else:
+        subprocess.check_call(["make", "-s", "-j4", "-C", os.path.join(_HERE, "csrc")])
+    return LIB_PATH
+
+
+def lib():
+    global _LIB
+    if _LIB is not None:
+        return _LIB
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(f"{LIB_PATH} is missing: run __graft_entry__.build() (hipcc --offload-arch=gfx950); "
+                          "azdopt_amd has no CPU fallback")
+    L = C.CDLL(LIB_PATH)
+    vp, i32p, u64p, f32p = C.c_void_p, C.POINTER(C.c_int32), C.POINTER(C.c_uint64), C.POINTER(C.c_float)
+
+    def sig(name, res, *args):
+        f = getattr(L, name)
+        f.restype = res
+        f.argtypes = list(args)
+
+    sig("azd_status_string", C.c_char_p, C.c_int)
+    sig("azd_last_error", C.c_char_p)
+    sig("azd_version", C.c_int)
+    sig("azd_device_count", C.c_int)
+    sig("azd_c21_state_dim", C.c_int, C.c_int)
+    sig("azd_c21_action_dim", C.c_int, C.c_int)
+    sig("azd_c21_key_words", C.c_int, C.c_int)
+    sig("azd_c21_generate_roots", C.c_int, C.c_uint64, C.c_uint64, C.c_uint64, C.c_int, C.c_int, C.c_int, C.c_int, vp, vp)
+    sig("azd_evaluator_create_mlp", C.c_int, C.POINTER(vp), C.c_int, C.c_int, C.c_int, C.c_int, vp, C.c_int, C.c_int,
+        C.POINTER(AdamConfig), C.c_uint64)
+    sig("azd_evaluator_create_trivial", C.c_int, C.POINTER(vp), C.c_int, C.c_int, C.c_int)
+    sig("azd_evaluator_create_hash_stream", C.c_int, C.POINTER(vp), C.c_int, C.c_int, C.c_int, C.c_uint64, C.c_uint64)
+    sig("azd_evaluator_destroy", C.c_int, vp)
+    sig("azd_evaluator_write_predictions", C.c_int, vp, C.c_int, vp, vp)
+    sig("azd_evaluator_update_model", C.c_int, vp, C.c_int, vp, vp, vp, f32p)
+    sig("azd_evaluator_write_predictions_dev", C.c_int, vp, C.c_int, vp, vp, vp)
+    sig("azd_evaluator_update_model_dev", C.c_int, vp, C.c_int, vp, vp, vp, f32p, vp)
+    sig("azd_evaluator_num_params", C.c_int64, vp)
+    sig("azd_evaluator_get_params", C.c_int, vp, vp)
+    sig("azd_evaluator_set_params", C.c_int, vp, vp)
+    sig("azd_evaluator_calls", C.c_uint64, vp)
+    sig("azd_engine_create", C.c_int, C.POINTER(vp), C.POINTER(EngineConfig), vp)
+    sig("azd_engine_destroy", C.c_int, vp)
+    sig("azd_engine_par_new", C.c_int, vp, vp, vp)
+    sig("azd_engine_par_roll_out_episodes", C.c_int, vp, vp, C.c_int, C.c_uint32, C.c_int, i32p)
+    sig("azd_engine_par_update_model", C.c_int, vp, C.c_uint32, f32p)
+    sig("azd_engine_par_reset_trees", C.c_int, vp, vp, vp)
+    sig("azd_engine_argmin_data", C.c_int, vp, C.POINTER(Argmin))
+    sig("azd_c21_modify_roots", C.c_int, vp, C.c_uint64, C.c_uint64, C.c_int, C.c_int, vp, vp)
+    sig("azd_engine_par_new_begin", C.c_int, vp, vp, vp)
+    sig("azd_engine_par_new_end", C.c_int, vp, vp)
+    sig("azd_engine_roll_out_begin", C.c_int, vp, vp, C.c_int, C.c_uint32)
+    sig("azd_engine_roll_out_end", C.c_int, vp, vp, i32p)
+    sig("azd_engine_reset_begin", C.c_int, vp, vp, vp)
+    sig("azd_engine_reset_end", C.c_int, vp, vp)
+    sig("azd_engine_observe", C.c_int, vp, C.c_uint32, vp, vp, vp)
+    sig("azd_engine_observe_dev", C.c_int, vp, C.c_uint32, C.POINTER(vp), C.POINTER(vp), C.POINTER(vp))
+    sig("azd_engine_read_state_vecs", C.c_int, vp, vp)
+    sig("azd_engine_read_predictions", C.c_int, vp, vp)
+    sig("azd_engine_tree_sizes", C.c_int, vp, C.c_int, i32p, i32p, i32p)
+    sig("azd_engine_export_tree", C.c_int, vp, C.c_int, *([vp] * 13))
+    sig("azd_engine_agent_state", C.c_int, vp, C.c_int, vp, vp, vp, C.POINTER(C.c_uint32), C.POINTER(C.c_double), i32p)
+    sig("azd_engine_counters", C.c_int, vp, vp)
+    sig("azd_engine_set_timing", C.c_int, vp, C.c_int)
+    sig("azd_engine_timing", C.c_int, vp, C.POINTER(C.c_double), C.POINTER(C.c_double), u64p)
+    sig("azd_engine_stream", vp, vp)
+    sig("azd_debug_probe_math", C.c_int, C.c_int, vp, vp, C.c_int)
+    _LIB = L
+    return L
+
+
+def check(status, where):
+    if status != 0:
+        raise AzdError(status, where)
+
+
+def ptr(a):
+    return a.ctypes.data_as(C.c_void_p)

@@ -1,0 +1,67 @@
+// c21_host.cpp -- host side of the c21 space seam: dimensions and the seeded root generator
+// that stands in for the driver's `init_states` closure (graph-state/examples/04-c21-tree.rs:108-112,
+// graph-state/src/rooted_tree/mod.rs:14-20, modify_parent_once.rs:14-25; the reference draws from
+// thread_rng, this build from a counter-based generator so that runs are reproducible and
+// shard-invariant -- the stream of an agent depends only on (seed, epoch, global agent id)).
+#include "c21_host.h"
+
+#include <vector>
+
+namespace azd {
+
+uint64_t splitmix64(uint64_t x) {
+    x += 0x9E3779B97F4A7C15ull;
+    x = (x ^ (x >> 30)) * 0xBF58476D1CE4E5B9ull;
+    x = (x ^ (x >> 27)) * 0x94D049BB133111EBull;
+    return x ^ (x >> 31);
+}
+uint64_t stream_key(uint64_t seed, uint64_t domain, uint64_t agent, uint64_t draw) {
+    return splitmix64(splitmix64(splitmix64(splitmix64(seed) ^ domain) ^ agent) ^ draw);
+}
+uint32_t draw_below(uint64_t r, uint32_t n) { return (uint32_t)(((r >> 32) * (uint64_t)n) >> 32); }
+
+int c21_state_dim(int n) { return (n - 1) * (n - 2) - 2; }
+int c21_action_dim(int n) { return (n - 1) * (n - 2) / 2 - 1; }
+int c21_key_words(int n) { return (c21_action_dim(n) + 63) / 64; }
+
+float c21_eval_slope(int n) { // 04-c21-tree.rs:58-74
+    int r = 0;
+    while ((r + 1) * (r + 1) <= n - 1) ++r;
+    int sq = (r * r == n - 1) ? r : r + 1;
+    int upper = sq + (n + 1) / 2;
+    return 1.0f / (float)(upper - 2);
+}
+
+void c21_shuffle_permitted(uint64_t seed, uint64_t domain, uint64_t agent, int n, int k, uint64_t *permitted) {
+    const int A = c21_action_dim(n), KW = c21_key_words(n);
+    std::vector<uint32_t> perm((size_t)A);
+    for (int i = 0; i < A; ++i) perm[(size_t)i] = (uint32_t)i;
+    for (int w = 0; w < KW; ++w) permitted[w] = 0;
+    for (int j = 0; j < k; ++j) {
+        uint32_t r = (uint32_t)j + draw_below(stream_key(seed, domain, agent, 64 + (uint64_t)j), (uint32_t)(A - j));
+        uint32_t tmp = perm[(size_t)j];
+        perm[(size_t)j] = perm[r];
+        perm[r] = tmp;
+        permitted[perm[(size_t)j] >> 6] |= 1ull << (perm[(size_t)j] & 63);
+    }
+}
+
+void c21_fresh_root(uint64_t seed, uint64_t domain, uint64_t agent, int n, int k, uint8_t *parents,
+                    uint64_t *permitted) {
+    for (int v = 0; v < n; ++v) parents[v] = 0;
+    for (int v = 2; v <= n - 2; ++v) parents[v] = (uint8_t)draw_below(stream_key(seed, domain, agent, (uint64_t)v), (uint32_t)v);
+    c21_shuffle_permitted(seed, domain, agent, n, k, permitted);
+}
+
+void c21_generate_roots(uint64_t seed, uint64_t epoch, uint64_t first_agent, int count, int n, int kmin, int kmax,
+                        uint8_t *parents, uint64_t *permitted) {
+    const int KW = c21_key_words(n);
+    const uint64_t domain = DOMAIN_ROOT ^ (epoch << 32);
+    for (int i = 0; i < count; ++i) {
+        uint64_t agent = first_agent + (uint64_t)i;
+        int k = kmin + (int)draw_below(stream_key(seed, domain, agent, 0), (uint32_t)(kmax - kmin + 1));
+        c21_fresh_root(seed, domain, agent, n, k, parents + (size_t)i * n, permitted + (size_t)i * KW);
+    }
+}
+
+} // namespace azd

@@ -1,0 +1,26 @@
+// c21_host.h -- host-side helpers of the c21 space seam (see c21_host.cpp)
+#pragma once
+#include <stdint.h>
+
+namespace azd {
+
+constexpr uint64_t DOMAIN_ROOT = 0x726f6f74ull;  // "root"
+constexpr uint64_t DOMAIN_PRED = 0x70726564ull;  // "pred"
+constexpr uint64_t DOMAIN_RESET = 0x72657365ull; // "rese"
+
+uint64_t splitmix64(uint64_t x);
+uint64_t stream_key(uint64_t seed, uint64_t domain, uint64_t agent, uint64_t draw);
+uint32_t draw_below(uint64_t r, uint32_t n);
+
+int c21_state_dim(int n);
+int c21_action_dim(int n);
+int c21_key_words(int n);
+float c21_eval_slope(int n);
+
+void c21_shuffle_permitted(uint64_t seed, uint64_t domain, uint64_t agent, int n, int k, uint64_t *permitted);
+void c21_fresh_root(uint64_t seed, uint64_t domain, uint64_t agent, int n, int k, uint8_t *parents,
+                    uint64_t *permitted);
+void c21_generate_roots(uint64_t seed, uint64_t epoch, uint64_t first_agent, int count, int n, int kmin, int kmax,
+                        uint8_t *parents, uint64_t *permitted);
+
+} // namespace azd

@@ -1,0 +1,881 @@
+// engine.hip -- host side of the C ABI (include/azdopt_amd.h): owns the device arenas,
+// sequences the kernels of one NablaOptimizer call on a HIP stream, copies results out.
+// No CPU fallback: every compute entry point needs a gfx950 device.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cstdio>
+#include <cstring>
+#include <new>
+#include <string>
+#include <vector>
+
+#include "../../include/azdopt_amd.h"
+#include "c21_host.h"
+#include "engine_types.h"
+#include "evaluator.h"
+
+namespace azd {
+
+thread_local std::string g_last_error;
+
+int hip_fail(hipError_t e, const char *what) {
+    g_last_error = std::string(what) + ": " + hipGetErrorString(e);
+    if (e == hipErrorNoDevice || e == hipErrorInvalidDevice) return AZD_ERR_NO_DEVICE;
+    if (e == hipErrorOutOfMemory) return AZD_ERR_OUT_OF_MEMORY;
+    return AZD_ERR_HIP;
+}
+
+static int device_ok(int device) {
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess || n <= 0) {
+        g_last_error = "no HIP device visible (this library has no CPU fallback)";
+        return AZD_ERR_NO_DEVICE;
+    }
+    if (device < 0 || device >= n) {
+        g_last_error = "device ordinal out of range";
+        return AZD_ERR_INVALID_ARGUMENT;
+    }
+    return AZD_OK;
+}
+
+// ------------------------------------------------------------------ simple evaluators
+struct TrivialEvaluator : azd_evaluator { // TrivialModel, model/mod.rs:10-23
+    int write_predictions_dev(int, const float *, float *, hipStream_t) override {
+        calls += 1;
+        return AZD_OK;
+    }
+    int update_model_dev(int, const float *, const float *, const float *, float *loss, hipStream_t) override {
+        if (loss) *loss = 0.f;
+        return AZD_OK;
+    }
+};
+
+struct HashStreamEvaluator : azd_evaluator {
+    uint64_t seed = 0, first_agent = 0;
+    int write_predictions_dev(int batch, const float *, float *d_p, hipStream_t st) override {
+        launch_hash_predictions(d_p, batch, action_dim, seed, first_agent, calls, st);
+        calls += 1;
+        AZD_HIP(hipGetLastError());
+        return AZD_OK;
+    }
+    int update_model_dev(int, const float *, const float *, const float *, float *loss, hipStream_t) override {
+        if (loss) *loss = 0.f;
+        return AZD_OK;
+    }
+};
+
+} // namespace azd
+
+azd_evaluator::~azd_evaluator() {
+    if (d_states) (void)hipFree(d_states);
+    if (d_preds) (void)hipFree(d_preds);
+    if (d_obs) (void)hipFree(d_obs);
+    if (d_w) (void)hipFree(d_w);
+    if (own_stream) (void)hipStreamDestroy(own_stream);
+}
+
+int azd_evaluator::ensure_staging(int batch) {
+    AZD_HIP(hipSetDevice(device));
+    if (!own_stream) AZD_HIP(hipStreamCreate(&own_stream));
+    if (batch <= staged_batch) return AZD_OK;
+    if (d_states) (void)hipFree(d_states);
+    if (d_preds) (void)hipFree(d_preds);
+    if (d_obs) (void)hipFree(d_obs);
+    if (d_w) (void)hipFree(d_w);
+    d_states = d_preds = d_obs = d_w = nullptr;
+    staged_batch = 0;
+    AZD_HIP(hipMalloc(&d_states, (size_t)batch * state_dim * sizeof(float)));
+    AZD_HIP(hipMalloc(&d_preds, (size_t)batch * action_dim * sizeof(float)));
+    AZD_HIP(hipMalloc(&d_obs, (size_t)batch * action_dim * sizeof(float)));
+    AZD_HIP(hipMalloc(&d_w, (size_t)batch * action_dim * sizeof(float)));
+    staged_batch = batch;
+    return AZD_OK;
+}
+
+// ------------------------------------------------------------------ engine
+struct azd_engine {
+    azd_engine_config cfg;
+    azd::Arenas a;
+    azd_evaluator *ev = nullptr;
+    hipStream_t stream = nullptr;
+    std::vector<void *> allocs;
+    uint8_t *d_stage_parents = nullptr;
+    uint64_t *d_stage_perm = nullptr;
+    azd::StatusRec *h_status = nullptr; // pinned
+    azd::ArgminRec *h_argmin = nullptr; // pinned
+    unsigned long long seen_improved = 0;
+    bool timing = false;
+    double rollout_ms = 0, evaluator_ms = 0;
+    uint64_t rollout_launches = 0;
+    std::vector<hipEvent_t> ev_pool;
+    std::vector<std::pair<int, std::pair<hipEvent_t, hipEvent_t>>> ev_inflight; // kind 0 rollout, 1 evaluator
+    bool initialised = false;
+
+    template <typename T>
+    int alloc(T **p, size_t count) {
+        void *q = nullptr;
+        hipError_t e = hipMalloc(&q, count * sizeof(T));
+        if (e != hipSuccess) return azd::hip_fail(e, "hipMalloc");
+        allocs.push_back(q);
+        *p = (T *)q;
+        return AZD_OK;
+    }
+    hipEvent_t get_event() {
+        if (!ev_pool.empty()) {
+            hipEvent_t e = ev_pool.back();
+            ev_pool.pop_back();
+            return e;
+        }
+        hipEvent_t e;
+        (void)hipEventCreate(&e);
+        return e;
+    }
+    void time_begin(int kind) {
+        if (!timing) return;
+        hipEvent_t b = get_event(), en = get_event();
+        (void)hipEventRecord(b, stream);
+        ev_inflight.push_back({kind, {b, en}});
+    }
+    void time_end() {
+        if (!timing) return;
+        (void)hipEventRecord(ev_inflight.back().second.second, stream);
+    }
+    void time_collect() { // after a stream sync
+        for (auto &it : ev_inflight) {
+            float ms = 0.f;
+            (void)hipEventElapsedTime(&ms, it.second.first, it.second.second);
+            if (it.first == 0) {
+                rollout_ms += ms;
+                rollout_launches += 1;
+            } else evaluator_ms += ms;
+            ev_pool.push_back(it.second.first);
+            ev_pool.push_back(it.second.second);
+        }
+        ev_inflight.clear();
+    }
+};
+
+namespace {
+
+using namespace azd;
+
+int next_pow2(int v) {
+    int p = 128;
+    while (p < v) p <<= 1;
+    return p;
+}
+
+int sync_status(azd_engine *e) {
+    AZD_HIP(hipMemcpyAsync(e->h_status, e->a.status, sizeof(StatusRec), hipMemcpyDeviceToHost, e->stream));
+    AZD_HIP(hipStreamSynchronize(e->stream));
+    e->time_collect();
+    AZD_HIP(hipGetLastError());
+    if (e->h_status->failed != 0) {
+        // distinguish capacity from unreachable by reading the flags
+        std::vector<uint32_t> fl((size_t)e->a.B);
+        AZD_HIP(hipMemcpy(fl.data(), e->a.flags, fl.size() * 4, hipMemcpyDeviceToHost));
+        uint32_t all = 0;
+        for (uint32_t f : fl) all |= f;
+        char buf[128];
+        snprintf(buf, sizeof(buf), "%llu agent(s) stopped, flag union 0x%x", e->h_status->failed, all);
+        g_last_error = buf;
+        return (all & (FLAG_UNREACHABLE | FLAG_LOOP_GUARD)) ? AZD_ERR_UNREACHABLE : AZD_ERR_CAPACITY;
+    }
+    return AZD_OK;
+}
+
+int upload_roots(azd_engine *e, const uint8_t *parents, const uint64_t *permitted) {
+    const Arenas &a = e->a;
+    // validate on the host what the kernels assume (parents[v] < v; at most MAX_NODE_ACTIONS permitted)
+    for (int i = 0; i < a.B; ++i) {
+        const uint8_t *p = parents + (size_t)i * a.n;
+        if (p[0] != 0) return AZD_ERR_INVALID_ARGUMENT;
+        for (int v = 1; v < a.n; ++v)
+            if (p[v] >= v) {
+                g_last_error = "root parents[v] must be < v";
+                return AZD_ERR_INVALID_ARGUMENT;
+            }
+        int cnt = 0;
+        for (int w = 0; w < a.KW; ++w) {
+            uint64_t m = permitted[(size_t)i * a.KW + w];
+            int hi = a.A - 64 * w;
+            if (hi < 64 && hi > 0 && (m >> hi) != 0) {
+                g_last_error = "permitted mask has bits beyond ACTION_DIM";
+                return AZD_ERR_INVALID_ARGUMENT;
+            }
+            cnt += __builtin_popcountll(m);
+        }
+        if (cnt > MAX_NODE_ACTIONS) {
+            g_last_error = "more permitted actions than a node can hold";
+            return AZD_ERR_INVALID_ARGUMENT;
+        }
+    }
+    AZD_HIP(hipMemcpyAsync(e->d_stage_parents, parents, (size_t)a.B * a.n, hipMemcpyHostToDevice, e->stream));
+    AZD_HIP(hipMemcpyAsync(e->d_stage_perm, permitted, (size_t)a.B * a.KW * 8, hipMemcpyHostToDevice, e->stream));
+    return AZD_OK;
+}
+
+int run_evaluator(azd_engine *e) {
+    e->time_begin(1);
+    int st = e->ev->write_predictions_dev(e->a.B, e->a.state_vecs, e->a.h_theta, e->stream);
+    e->time_end();
+    return st;
+}
+
+int fill_tol(TolTable &t, const uint32_t *tol, int n_tol, uint32_t dflt) {
+    if (n_tol < 0 || n_tol > MAX_TOL || (n_tol > 0 && !tol)) return AZD_ERR_INVALID_ARGUMENT;
+    for (int i = 0; i < MAX_TOL; ++i) t.tol[i] = i < n_tol ? tol[i] : dflt;
+    t.n_tol = n_tol;
+    t.tol_default = dflt;
+    return AZD_OK;
+}
+
+} // namespace
+
+extern "C" {
+
+const char *azd_status_string(int s) {
+    switch (s) {
+    case AZD_OK: return "ok";
+    case AZD_ERR_INVALID_ARGUMENT: return "invalid argument";
+    case AZD_ERR_NO_DEVICE: return "no gfx950 device (no CPU fallback)";
+    case AZD_ERR_HIP: return "HIP runtime error";
+    case AZD_ERR_CAPACITY: return "tree arena capacity exceeded";
+    case AZD_ERR_UNREACHABLE: return "unreachable selection state";
+    case AZD_ERR_NO_EVALUATOR: return "engine has no evaluator";
+    case AZD_ERR_OUT_OF_MEMORY: return "out of device memory";
+    case AZD_ERR_UNSUPPORTED: return "unsupported";
+    default: return "unknown status";
+    }
+}
+const char *azd_last_error(void) { return azd::g_last_error.c_str(); }
+int azd_version(void) { return 100; }
+int azd_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+int azd_c21_state_dim(int n) { return azd::c21_state_dim(n); }
+int azd_c21_action_dim(int n) { return azd::c21_action_dim(n); }
+int azd_c21_key_words(int n) { return azd::c21_key_words(n); }
+int azd_c21_generate_roots(uint64_t seed, uint64_t epoch, uint64_t first_agent, int count, int n, int kmin,
+                           int kmax, uint8_t *parents, uint64_t *permitted) {
+    if (n < 4 || n > AZD_C21_MAX_N || count < 0 || !parents || !permitted) return AZD_ERR_INVALID_ARGUMENT;
+    int A = azd::c21_action_dim(n);
+    if (kmin < 0 || kmax < kmin || kmax > A || kmax > azd::MAX_NODE_ACTIONS) return AZD_ERR_INVALID_ARGUMENT;
+    azd::c21_generate_roots(seed, epoch, first_agent, count, n, kmin, kmax, parents, permitted);
+    return AZD_OK;
+}
+
+// ------------------------------------------------------------------ evaluator ABI
+int azd_evaluator_create_mlp(azd_evaluator **out, int device, int max_batch, int state_dim, int action_dim,
+                             const int *hidden, int n_hidden, int final_act, const azd_adam_config *adam,
+                             uint64_t seed) {
+    if (!out || max_batch <= 0 || state_dim <= 0 || action_dim <= 0 || n_hidden < 0 || (n_hidden && !hidden) || !adam)
+        return AZD_ERR_INVALID_ARGUMENT;
+    int st = azd::device_ok(device);
+    if (st) return st;
+    azd_evaluator *ev = azd::make_mlp_evaluator(device, max_batch, state_dim, action_dim, hidden, n_hidden, final_act, adam, seed, &st);
+    if (!ev) return st;
+    *out = ev;
+    return AZD_OK;
+}
+int azd_evaluator_create_trivial(azd_evaluator **out, int device, int state_dim, int action_dim) {
+    if (!out) return AZD_ERR_INVALID_ARGUMENT;
+    int st = azd::device_ok(device);
+    if (st) return st;
+    auto *ev = new (std::nothrow) azd::TrivialEvaluator();
+    if (!ev) return AZD_ERR_OUT_OF_MEMORY;
+    ev->device = device;
+    ev->state_dim = state_dim;
+    ev->action_dim = action_dim;
+    *out = ev;
+    return AZD_OK;
+}
+int azd_evaluator_create_hash_stream(azd_evaluator **out, int device, int state_dim, int action_dim, uint64_t seed,
+                                     uint64_t first_agent) {
+    if (!out) return AZD_ERR_INVALID_ARGUMENT;
+    int st = azd::device_ok(device);
+    if (st) return st;
+    auto *ev = new (std::nothrow) azd::HashStreamEvaluator();
+    if (!ev) return AZD_ERR_OUT_OF_MEMORY;
+    ev->device = device;
+    ev->state_dim = state_dim;
+    ev->action_dim = action_dim;
+    ev->seed = seed;
+    ev->first_agent = first_agent;
+    *out = ev;
+    return AZD_OK;
+}
+int azd_evaluator_destroy(azd_evaluator *ev) {
+    delete ev;
+    return AZD_OK;
+}
+int azd_evaluator_write_predictions(azd_evaluator *ev, int batch, const float *states, float *predictions) {
+    if (!ev || batch <= 0 || !states || !predictions) return AZD_ERR_INVALID_ARGUMENT;
+    int st = ev->ensure_staging(batch);
+    if (st) return st;
+    size_t sb = (size_t)batch * ev->state_dim * 4, pb = (size_t)batch * ev->action_dim * 4;
+    AZD_HIP(hipMemcpyAsync(ev->d_states, states, sb, hipMemcpyHostToDevice, ev->own_stream));
+    // TrivialModel must leave the caller's buffer untouched: seed the staging copy with it
+    AZD_HIP(hipMemcpyAsync(ev->d_preds, predictions, pb, hipMemcpyHostToDevice, ev->own_stream));
+    st = ev->write_predictions_dev(batch, ev->d_states, ev->d_preds, ev->own_stream);
+    if (st) return st;
+    AZD_HIP(hipMemcpyAsync(predictions, ev->d_preds, pb, hipMemcpyDeviceToHost, ev->own_stream));
+    AZD_HIP(hipStreamSynchronize(ev->own_stream));
+    return AZD_OK;
+}
+int azd_evaluator_update_model(azd_evaluator *ev, int batch, const float *states, const float *observations,
+                               const float *action_weights, float *loss) {
+    if (!ev || batch <= 0 || !states || !observations || !action_weights) return AZD_ERR_INVALID_ARGUMENT;
+    int st = ev->ensure_staging(batch);
+    if (st) return st;
+    size_t sb = (size_t)batch * ev->state_dim * 4, pb = (size_t)batch * ev->action_dim * 4;
+    AZD_HIP(hipMemcpyAsync(ev->d_states, states, sb, hipMemcpyHostToDevice, ev->own_stream));
+    AZD_HIP(hipMemcpyAsync(ev->d_obs, observations, pb, hipMemcpyHostToDevice, ev->own_stream));
+    AZD_HIP(hipMemcpyAsync(ev->d_w, action_weights, pb, hipMemcpyHostToDevice, ev->own_stream));
+    return ev->update_model_dev(batch, ev->d_states, ev->d_obs, ev->d_w, loss, ev->own_stream);
+}
+int azd_evaluator_write_predictions_dev(azd_evaluator *ev, int batch, const float *d_states, float *d_predictions,
+                                        void *stream) {
+    if (!ev || batch <= 0) return AZD_ERR_INVALID_ARGUMENT;
+    AZD_HIP(hipSetDevice(ev->device));
+    return ev->write_predictions_dev(batch, d_states, d_predictions, (hipStream_t)stream);
+}
+int azd_evaluator_update_model_dev(azd_evaluator *ev, int batch, const float *d_states, const float *d_observations,
+                                   const float *d_action_weights, float *loss, void *stream) {
+    if (!ev || batch <= 0) return AZD_ERR_INVALID_ARGUMENT;
+    AZD_HIP(hipSetDevice(ev->device));
+    return ev->update_model_dev(batch, d_states, d_observations, d_action_weights, loss, (hipStream_t)stream);
+}
+int64_t azd_evaluator_num_params(azd_evaluator *ev) { return ev ? ev->num_params() : 0; }
+int azd_evaluator_get_params(azd_evaluator *ev, float *out) { return ev && out ? ev->get_params(out) : AZD_ERR_INVALID_ARGUMENT; }
+int azd_evaluator_set_params(azd_evaluator *ev, const float *in) { return ev && in ? ev->set_params(in) : AZD_ERR_INVALID_ARGUMENT; }
+uint64_t azd_evaluator_calls(azd_evaluator *ev) { return ev ? ev->calls : 0; }
+
+// ------------------------------------------------------------------ engine ABI
+int azd_engine_create(azd_engine **out, const azd_engine_config *cfg, azd_evaluator *ev) {
+    if (!out || !cfg) return AZD_ERR_INVALID_ARGUMENT;
+    if (cfg->space_id != AZD_SPACE_C21 || cfg->n < 4 || cfg->n > AZD_C21_MAX_N || cfg->batch <= 0) {
+        azd::g_last_error = "unsupported space / n / batch";
+        return AZD_ERR_INVALID_ARGUMENT;
+    }
+    int st = azd::device_ok(cfg->device);
+    if (st) return st;
+    AZD_HIP(hipSetDevice(cfg->device));
+    azd_engine *e = new (std::nothrow) azd_engine();
+    if (!e) return AZD_ERR_OUT_OF_MEMORY;
+    e->cfg = *cfg;
+    e->ev = ev;
+    azd::Arenas &a = e->a;
+    memset(&a, 0, sizeof(a));
+    a.n = cfg->n;
+    a.A = azd::c21_action_dim(cfg->n);
+    a.S = azd::c21_state_dim(cfg->n);
+    a.KW = azd::c21_key_words(cfg->n);
+    a.B = cfg->batch;
+    a.eval_slope = azd::c21_eval_slope(cfg->n);
+    if (ev && (ev->state_dim != a.S || ev->action_dim != a.A)) {
+        delete e;
+        azd::g_last_error = "evaluator dimensions do not match the space";
+        return AZD_ERR_INVALID_ARGUMENT;
+    }
+    a.node_cap = cfg->node_capacity > 0 ? (uint32_t)cfg->node_capacity : 4096u;
+    a.arc_cap = cfg->arc_capacity > 0 ? (uint32_t)cfg->arc_capacity : 8192u;
+    a.pred_cap = cfg->prediction_capacity > 0 ? (uint32_t)cfg->prediction_capacity : 32768u;
+    a.ht_cap = (uint32_t)next_pow2((int)(2 * a.node_cap));
+    const size_t B = (size_t)a.B;
+#define TRY(x)              \
+    do {                    \
+        st = (x);           \
+        if (st) {           \
+            azd_engine_destroy(e); \
+            return st;      \
+        }                   \
+    } while (0)
+    {
+        hipError_t he = hipStreamCreate(&e->stream);
+        if (he != hipSuccess) {
+            st = azd::hip_fail(he, "hipStreamCreate");
+            delete e;
+            return st;
+        }
+    }
+    TRY(e->alloc(&a.nodes, B * a.node_cap));
+    TRY(e->alloc(&a.keys, B * a.node_cap * a.KW));
+    TRY(e->alloc(&a.arcs, B * a.arc_cap));
+    TRY(e->alloc(&a.preds, B * a.pred_cap));
+    TRY(e->alloc(&a.ht, B * a.ht_cap));
+    TRY(e->alloc(&a.root_parents, B * azd::PARENTS_STRIDE));
+    TRY(e->alloc(&a.cur_parents, B * azd::PARENTS_STRIDE));
+    TRY(e->alloc(&a.root_perm, B * a.KW));
+    TRY(e->alloc(&a.cur_perm, B * a.KW));
+    TRY(e->alloc(&a.cur_path, B * a.KW));
+    TRY(e->alloc(&a.cur_lambda, B));
+    TRY(e->alloc(&a.cur_mu, B));
+    TRY(e->alloc(&a.state_pos, B));
+    TRY(e->alloc(&a.n_nodes, B));
+    TRY(e->alloc(&a.n_arcs, B));
+    TRY(e->alloc(&a.n_preds, B));
+    TRY(e->alloc(&a.flags, B));
+    TRY(e->alloc(&a.cand_c, B));
+    TRY(e->alloc(&a.cand_node, B));
+    TRY(e->alloc(&a.counters, B * azd::NUM_COUNTERS));
+    TRY(e->alloc(&a.state_vecs, B * a.S));
+    TRY(e->alloc(&a.h_theta, B * a.A));
+    a.obs = a.h_theta; // the reference reuses h_theta_host as the observation buffer (optimizer/mod.rs:270-277)
+    TRY(e->alloc(&a.weights, B * a.A));
+    TRY(e->alloc(&a.argmin, 1));
+    TRY(e->alloc(&a.status, 1));
+    TRY(e->alloc(&e->d_stage_parents, B * a.n));
+    TRY(e->alloc(&e->d_stage_perm, B * a.KW));
+    {
+        hipError_t he = hipHostMalloc((void **)&e->h_status, sizeof(azd::StatusRec));
+        if (he == hipSuccess) he = hipHostMalloc((void **)&e->h_argmin, sizeof(azd::ArgminRec));
+        if (he != hipSuccess) {
+            st = azd::hip_fail(he, "hipHostMalloc");
+            azd_engine_destroy(e);
+            return st;
+        }
+    }
+    hipError_t he = hipMemsetAsync(a.counters, 0, B * azd::NUM_COUNTERS * 8, e->stream);
+    if (he == hipSuccess) he = hipMemsetAsync(a.status, 0, sizeof(azd::StatusRec), e->stream);
+    if (he == hipSuccess) he = hipMemsetAsync(a.argmin, 0, sizeof(azd::ArgminRec), e->stream);
+    if (he == hipSuccess) he = hipMemsetAsync(a.flags, 0, B * 4, e->stream);
+    if (he == hipSuccess) he = hipMemsetAsync(a.h_theta, 0, B * a.A * 4, e->stream);
+    if (he == hipSuccess) he = hipMemsetAsync(a.weights, 0, B * a.A * 4, e->stream);
+    if (he == hipSuccess) he = hipStreamSynchronize(e->stream);
+    if (he != hipSuccess) {
+        st = azd::hip_fail(he, "engine init memset");
+        azd_engine_destroy(e);
+        return st;
+    }
+#undef TRY
+    *out = e;
+    return AZD_OK;
+}
+
+int azd_engine_destroy(azd_engine *e) {
+    if (!e) return AZD_OK;
+    (void)hipSetDevice(e->cfg.device);
+    if (e->stream) (void)hipStreamSynchronize(e->stream);
+    for (void *p : e->allocs) (void)hipFree(p);
+    if (e->h_status) (void)hipHostFree(e->h_status);
+    if (e->h_argmin) (void)hipHostFree(e->h_argmin);
+    for (auto &it : e->ev_inflight) {
+        (void)hipEventDestroy(it.second.first);
+        (void)hipEventDestroy(it.second.second);
+    }
+    for (hipEvent_t ev : e->ev_pool) (void)hipEventDestroy(ev);
+    if (e->stream) (void)hipStreamDestroy(e->stream);
+    delete e;
+    return AZD_OK;
+}
+
+// optimizer/mod.rs:61-70
+int azd_engine_par_new_begin(azd_engine *e, const uint8_t *parents, const uint64_t *permitted) {
+    if (!e || !parents || !permitted) return AZD_ERR_INVALID_ARGUMENT;
+    AZD_HIP(hipSetDevice(e->cfg.device));
+    int st = upload_roots(e, parents, permitted);
+    if (st) return st;
+    const azd::Arenas &a = e->a;
+    AZD_HIP(hipMemsetAsync(a.counters, 0, (size_t)a.B * azd::NUM_COUNTERS * 8, e->stream));
+    AZD_HIP(hipMemsetAsync(a.status, 0, sizeof(azd::StatusRec), e->stream));
+    e->seen_improved = 0;
+    azd::launch_init_roots(a, e->d_stage_parents, e->d_stage_perm, e->stream);
+    AZD_HIP(hipMemsetAsync(a.h_theta, 0, (size_t)a.B * a.A * 4, e->stream)); // vec![0.; ..] at :71
+    AZD_HIP(hipGetLastError());
+    return AZD_OK;
+}
+static int new_finish(azd_engine *e) {
+    azd::launch_add_actions(e->a, 1, e->stream);
+    azd::launch_argmin(e->a, 1, e->stream);
+    e->initialised = true;
+    return sync_status(e);
+}
+// optimizer/mod.rs:74-101
+int azd_engine_par_new_end(azd_engine *e, const float *h_theta) {
+    if (!e || !h_theta) return AZD_ERR_INVALID_ARGUMENT;
+    AZD_HIP(hipSetDevice(e->cfg.device));
+    AZD_HIP(hipMemcpyAsync(e->a.h_theta, h_theta, (size_t)e->a.B * e->a.A * 4, hipMemcpyHostToDevice, e->stream));
+    return new_finish(e);
+}
+int azd_engine_par_new(azd_engine *e, const uint8_t *parents, const uint64_t *permitted) {
+    if (!e) return AZD_ERR_INVALID_ARGUMENT;
+    if (!e->ev) return AZD_ERR_NO_EVALUATOR;
+    int st = azd_engine_par_new_begin(e, parents, permitted);
+    if (st) return st;
+    st = run_evaluator(e); // :72
+    if (st) return st;
+    return new_finish(e);
+}
+
+// optimizer/mod.rs:159-174
+int azd_engine_roll_out_begin(azd_engine *e, const uint32_t *tol, int n_tol, uint32_t dflt) {
+    if (!e || !e->initialised) return AZD_ERR_INVALID_ARGUMENT;
+    AZD_HIP(hipSetDevice(e->cfg.device));
+    azd::TolTable t;
+    int st = fill_tol(t, tol, n_tol, dflt);
+    if (st) return st;
+    e->time_begin(0);
+    azd::launch_rollout(e->a, t, e->stream);
+    e->time_end();
+    return sync_status(e);
+}
+// optimizer/mod.rs:177-190
+int azd_engine_roll_out_end(azd_engine *e, const float *h_theta, int *improved) {
+    if (!e || !h_theta || !e->initialised) return AZD_ERR_INVALID_ARGUMENT;
+    AZD_HIP(hipSetDevice(e->cfg.device));
+    AZD_HIP(hipMemcpyAsync(e->a.h_theta, h_theta, (size_t)e->a.B * e->a.A * 4, hipMemcpyHostToDevice, e->stream));
+    azd::launch_add_actions(e->a, 0, e->stream);
+    azd::launch_argmin(e->a, 0, e->stream);
+    int st = sync_status(e);
+    if (improved) *improved = (int)(e->h_status->improved - e->seen_improved);
+    e->seen_improved = e->h_status->improved;
+    return st;
+}
+int azd_engine_par_roll_out_episodes(azd_engine *e, const uint32_t *tol, int n_tol, uint32_t dflt, int n_calls,
+                                     int *improved) {
+    if (!e || n_calls < 0 || !e->initialised) return AZD_ERR_INVALID_ARGUMENT;
+    if (!e->ev) return AZD_ERR_NO_EVALUATOR;
+    AZD_HIP(hipSetDevice(e->cfg.device));
+    azd::TolTable t;
+    int st = fill_tol(t, tol, n_tol, dflt);
+    if (st) return st;
+    for (int c = 0; c < n_calls; ++c) {
+        e->time_begin(0);
+        azd::launch_rollout(e->a, t, e->stream);
+        e->time_end();
+        st = run_evaluator(e); // :175-176
+        if (st) return st;
+        azd::launch_add_actions(e->a, 0, e->stream);
+        azd::launch_argmin(e->a, 0, e->stream); // :190
+    }
+    st = sync_status(e);
+    if (improved) *improved = (int)(e->h_status->improved - e->seen_improved);
+    e->seen_improved = e->h_status->improved;
+    return st;
+}
+
+// optimizer/mod.rs:262-278
+int azd_engine_observe_dev(azd_engine *e, uint32_t n_obs_tol, const float **d_state_vecs, const float **d_obs,
+                           const float **d_w) {
+    if (!e || !e->initialised) return AZD_ERR_INVALID_ARGUMENT;
+    AZD_HIP(hipSetDevice(e->cfg.device));
+    azd::launch_observe(e->a, n_obs_tol, e->stream);
+    AZD_HIP(hipStreamSynchronize(e->stream));
+    AZD_HIP(hipGetLastError());
+    if (d_state_vecs) *d_state_vecs = e->a.state_vecs;
+    if (d_obs) *d_obs = e->a.obs;
+    if (d_w) *d_w = e->a.weights;
+    return AZD_OK;
+}
+int azd_engine_observe(azd_engine *e, uint32_t n_obs_tol, float *state_vecs, float *observations, float *weights) {
+    int st = azd_engine_observe_dev(e, n_obs_tol, nullptr, nullptr, nullptr);
+    if (st) return st;
+    const azd::Arenas &a = e->a;
+    if (state_vecs) AZD_HIP(hipMemcpy(state_vecs, a.state_vecs, (size_t)a.B * a.S * 4, hipMemcpyDeviceToHost));
+    if (observations) AZD_HIP(hipMemcpy(observations, a.obs, (size_t)a.B * a.A * 4, hipMemcpyDeviceToHost));
+    if (weights) AZD_HIP(hipMemcpy(weights, a.weights, (size_t)a.B * a.A * 4, hipMemcpyDeviceToHost));
+    return AZD_OK;
+}
+int azd_engine_par_update_model(azd_engine *e, uint32_t n_obs_tol, float *loss) {
+    if (!e || !e->initialised) return AZD_ERR_INVALID_ARGUMENT;
+    if (!e->ev) return AZD_ERR_NO_EVALUATOR;
+    AZD_HIP(hipSetDevice(e->cfg.device));
+    azd::launch_observe(e->a, n_obs_tol, e->stream);
+    AZD_HIP(hipGetLastError());
+    float l = 0.f;
+    int st = e->ev->update_model_dev(e->a.B, e->a.state_vecs, e->a.obs, e->a.weights, &l, e->stream); // :279-280
+    if (st) return st;
+    AZD_HIP(hipStreamSynchronize(e->stream));
+    if (loss) *loss = l;
+    return AZD_OK;
+}
+
+// optimizer/mod.rs:317-346
+int azd_engine_reset_begin(azd_engine *e, const uint8_t *parents, const uint64_t *permitted) {
+    if (!e || !parents || !permitted || !e->initialised) return AZD_ERR_INVALID_ARGUMENT;
+    AZD_HIP(hipSetDevice(e->cfg.device));
+    int st = upload_roots(e, parents, permitted);
+    if (st) return st;
+    const azd::Arenas &a = e->a;
+    AZD_HIP(hipMemsetAsync(&a.status->failed, 0, sizeof(unsigned long long), e->stream));
+    azd::launch_init_roots(a, e->d_stage_parents, e->d_stage_perm, e->stream);
+    AZD_HIP(hipMemsetAsync(a.h_theta, 0, (size_t)a.B * a.A * 4, e->stream)); // h_theta_host.fill(0.) at :347
+    AZD_HIP(hipGetLastError());
+    return AZD_OK;
+}
+static int reset_finish(azd_engine *e) {
+    azd::launch_add_actions(e->a, 1, e->stream); // :350-358; num_inspected_nodes = 0 via cand_* in init_roots
+    return sync_status(e);
+}
+int azd_engine_reset_end(azd_engine *e, const float *h_theta) {
+    if (!e || !h_theta) return AZD_ERR_INVALID_ARGUMENT;
+    AZD_HIP(hipSetDevice(e->cfg.device));
+    AZD_HIP(hipMemcpyAsync(e->a.h_theta, h_theta, (size_t)e->a.B * e->a.A * 4, hipMemcpyHostToDevice, e->stream));
+    return reset_finish(e);
+}
+int azd_engine_par_reset_trees(azd_engine *e, const uint8_t *parents, const uint64_t *permitted) {
+    if (!e) return AZD_ERR_INVALID_ARGUMENT;
+    if (!e->ev) return AZD_ERR_NO_EVALUATOR;
+    int st = azd_engine_reset_begin(e, parents, permitted);
+    if (st) return st;
+    st = run_evaluator(e); // :348
+    if (st) return st;
+    return reset_finish(e);
+}
+
+int azd_engine_argmin_data(azd_engine *e, azd_argmin *out) {
+    if (!e || !out || !e->initialised) return AZD_ERR_INVALID_ARGUMENT;
+    AZD_HIP(hipSetDevice(e->cfg.device));
+    static_assert(sizeof(azd_argmin) == sizeof(azd::ArgminRec), "ABI struct mismatch");
+    AZD_HIP(hipMemcpyAsync(e->h_argmin, e->a.argmin, sizeof(azd::ArgminRec), hipMemcpyDeviceToHost, e->stream));
+    AZD_HIP(hipStreamSynchronize(e->stream));
+    memcpy(out, e->h_argmin, sizeof(azd_argmin));
+    return AZD_OK;
+}
+
+int azd_engine_read_state_vecs(azd_engine *e, float *out) {
+    if (!e || !out) return AZD_ERR_INVALID_ARGUMENT;
+    AZD_HIP(hipSetDevice(e->cfg.device));
+    AZD_HIP(hipStreamSynchronize(e->stream));
+    AZD_HIP(hipMemcpy(out, e->a.state_vecs, (size_t)e->a.B * e->a.S * 4, hipMemcpyDeviceToHost));
+    return AZD_OK;
+}
+int azd_engine_read_predictions(azd_engine *e, float *out) {
+    if (!e || !out) return AZD_ERR_INVALID_ARGUMENT;
+    AZD_HIP(hipSetDevice(e->cfg.device));
+    AZD_HIP(hipStreamSynchronize(e->stream));
+    AZD_HIP(hipMemcpy(out, e->a.h_theta, (size_t)e->a.B * e->a.A * 4, hipMemcpyDeviceToHost));
+    return AZD_OK;
+}
+
+int azd_engine_tree_sizes(azd_engine *e, int agent, int *n_nodes, int *n_arcs, int *n_preds) {
+    if (!e || agent < 0 || agent >= e->a.B) return AZD_ERR_INVALID_ARGUMENT;
+    AZD_HIP(hipSetDevice(e->cfg.device));
+    AZD_HIP(hipStreamSynchronize(e->stream));
+    uint32_t v[3];
+    AZD_HIP(hipMemcpy(&v[0], e->a.n_nodes + agent, 4, hipMemcpyDeviceToHost));
+    AZD_HIP(hipMemcpy(&v[1], e->a.n_arcs + agent, 4, hipMemcpyDeviceToHost));
+    AZD_HIP(hipMemcpy(&v[2], e->a.n_preds + agent, 4, hipMemcpyDeviceToHost));
+    if (n_nodes) *n_nodes = (int)v[0];
+    if (n_arcs) *n_arcs = (int)v[1];
+    if (n_preds) *n_preds = (int)v[2];
+    return AZD_OK;
+}
+
+int azd_engine_export_tree(azd_engine *e, int agent, float *c, float *c_star, uint32_t *n_t, uint32_t *exhausted,
+                           uint32_t *act_begin, uint32_t *act_end, uint64_t *keys, uint32_t *arc_src,
+                           uint32_t *arc_dst, uint32_t *arc_pp, uint32_t *pred_a_id, float *pred_g,
+                           int32_t *pred_arc) {
+    int nn, na, np;
+    int st = azd_engine_tree_sizes(e, agent, &nn, &na, &np);
+    if (st) return st;
+    const azd::Arenas &a = e->a;
+    std::vector<azd::NodeRec> nodes((size_t)nn);
+    std::vector<azd::ArcRec> arcs((size_t)na);
+    std::vector<azd::PredRec> preds((size_t)np);
+    AZD_HIP(hipMemcpy(nodes.data(), a.nodes + (size_t)agent * a.node_cap, nodes.size() * sizeof(azd::NodeRec), hipMemcpyDeviceToHost));
+    if (na) AZD_HIP(hipMemcpy(arcs.data(), a.arcs + (size_t)agent * a.arc_cap, arcs.size() * sizeof(azd::ArcRec), hipMemcpyDeviceToHost));
+    if (np) AZD_HIP(hipMemcpy(preds.data(), a.preds + (size_t)agent * a.pred_cap, preds.size() * sizeof(azd::PredRec), hipMemcpyDeviceToHost));
+    if (keys) AZD_HIP(hipMemcpy(keys, a.keys + (size_t)agent * a.node_cap * a.KW, (size_t)nn * a.KW * 8, hipMemcpyDeviceToHost));
+    for (int i = 0; i < nn; ++i) {
+        if (c) c[i] = nodes[(size_t)i].c;
+        if (c_star) c_star[i] = nodes[(size_t)i].c_star;
+        if (n_t) n_t[i] = nodes[(size_t)i].n_t;
+        if (exhausted) exhausted[i] = nodes[(size_t)i].exhausted;
+        if (act_begin) act_begin[i] = nodes[(size_t)i].act_begin;
+        if (act_end) act_end[i] = nodes[(size_t)i].act_end;
+    }
+    for (int i = 0; i < na; ++i) {
+        if (arc_src) arc_src[i] = arcs[(size_t)i].src;
+        if (arc_dst) arc_dst[i] = arcs[(size_t)i].dst;
+        if (arc_pp) arc_pp[i] = arcs[(size_t)i].pp;
+    }
+    for (int i = 0; i < np; ++i) {
+        if (pred_a_id) pred_a_id[i] = preds[(size_t)i].a_id;
+        if (pred_g) pred_g[i] = preds[(size_t)i].g;
+        if (pred_arc) pred_arc[i] = preds[(size_t)i].arc == azd::NONE ? -1 : (int32_t)preds[(size_t)i].arc;
+    }
+    return AZD_OK;
+}
+
+int azd_engine_agent_state(azd_engine *e, int agent, uint8_t *parents, uint64_t *permitted, uint64_t *path,
+                           uint32_t *state_pos, double *lambda_1, int *matching_size) {
+    if (!e || agent < 0 || agent >= e->a.B) return AZD_ERR_INVALID_ARGUMENT;
+    AZD_HIP(hipSetDevice(e->cfg.device));
+    AZD_HIP(hipStreamSynchronize(e->stream));
+    const azd::Arenas &a = e->a;
+    uint8_t par[azd::PARENTS_STRIDE];
+    AZD_HIP(hipMemcpy(par, a.cur_parents + (size_t)agent * azd::PARENTS_STRIDE, azd::PARENTS_STRIDE, hipMemcpyDeviceToHost));
+    if (parents) memcpy(parents, par, (size_t)a.n);
+    if (permitted) AZD_HIP(hipMemcpy(permitted, a.cur_perm + (size_t)agent * a.KW, (size_t)a.KW * 8, hipMemcpyDeviceToHost));
+    if (path) AZD_HIP(hipMemcpy(path, a.cur_path + (size_t)agent * a.KW, (size_t)a.KW * 8, hipMemcpyDeviceToHost));
+    if (state_pos) AZD_HIP(hipMemcpy(state_pos, a.state_pos + agent, 4, hipMemcpyDeviceToHost));
+    if (lambda_1) AZD_HIP(hipMemcpy(lambda_1, a.cur_lambda + agent, 8, hipMemcpyDeviceToHost));
+    if (matching_size) AZD_HIP(hipMemcpy(matching_size, a.cur_mu + agent, 4, hipMemcpyDeviceToHost));
+    return AZD_OK;
+}
+
+int azd_engine_counters(azd_engine *e, uint64_t *out) {
+    if (!e || !out) return AZD_ERR_INVALID_ARGUMENT;
+    AZD_HIP(hipSetDevice(e->cfg.device));
+    AZD_HIP(hipStreamSynchronize(e->stream));
+    const azd::Arenas &a = e->a;
+    std::vector<unsigned long long> h((size_t)a.B * azd::NUM_COUNTERS);
+    std::vector<uint32_t> fl((size_t)a.B);
+    AZD_HIP(hipMemcpy(h.data(), a.counters, h.size() * 8, hipMemcpyDeviceToHost));
+    AZD_HIP(hipMemcpy(fl.data(), a.flags, fl.size() * 4, hipMemcpyDeviceToHost));
+    for (int k = 0; k < AZD_CTR_COUNT; ++k) out[k] = 0;
+    for (int i = 0; i < a.B; ++i) {
+        for (int k = 0; k < azd::NUM_COUNTERS; ++k) {
+            unsigned long long v = h[(size_t)i * azd::NUM_COUNTERS + k];
+            if (k == AZD_CTR_MAX_FRONTIER || k == AZD_CTR_MAX_DEPTH) out[k] = std::max<uint64_t>(out[k], v);
+            else out[k] += v;
+        }
+    }
+    uint64_t failed = 0;
+    for (uint32_t f : fl) failed += f != 0;
+    out[AZD_CTR_FAILED_AGENTS] = failed;
+    return AZD_OK;
+}
+
+int azd_engine_set_timing(azd_engine *e, int enabled) {
+    if (!e) return AZD_ERR_INVALID_ARGUMENT;
+    e->timing = enabled != 0;
+    e->rollout_ms = e->evaluator_ms = 0;
+    e->rollout_launches = 0;
+    return AZD_OK;
+}
+int azd_engine_timing(azd_engine *e, double *tree_ms, double *evaluator_ms, uint64_t *tree_launches) {
+    if (!e) return AZD_ERR_INVALID_ARGUMENT;
+    if (tree_ms) *tree_ms = e->rollout_ms;
+    if (evaluator_ms) *evaluator_ms = e->evaluator_ms;
+    if (tree_launches) *tree_launches = e->rollout_launches;
+    return AZD_OK;
+}
+void *azd_engine_stream(azd_engine *e) { return e ? (void *)e->stream : nullptr; }
+
+int azd_debug_probe_math(int device, const float *in, float *out, int n) {
+    if (!in || !out || n <= 0) return AZD_ERR_INVALID_ARGUMENT;
+    int st = azd::device_ok(device);
+    if (st) return st;
+    AZD_HIP(hipSetDevice(device));
+    float *d_in = nullptr, *d_out = nullptr;
+    AZD_HIP(hipMalloc(&d_in, (size_t)n * 8));
+    AZD_HIP(hipMalloc(&d_out, (size_t)n * 8));
+    AZD_HIP(hipMemcpy(d_in, in, (size_t)n * 8, hipMemcpyHostToDevice));
+    azd::launch_probe_math(d_in, d_out, n, nullptr);
+    hipError_t he = hipDeviceSynchronize();
+    if (he == hipSuccess) he = hipMemcpy(out, d_out, (size_t)n * 8, hipMemcpyDeviceToHost);
+    (void)hipFree(d_in);
+    (void)hipFree(d_out);
+    if (he != hipSuccess) return azd::hip_fail(he, "probe_math");
+    return AZD_OK;
+}
+
+// ------------------------------------------------------------------ c21 root policy (host)
+// 04-c21-tree.rs:172-206 applied to node_data() (tree/mod.rs:302-307: BTreeMap order, i.e. keys
+// compared lexicographically over their ascending elements; n[0] is the root).
+static bool key_less(const uint64_t *x, const uint64_t *y, int KW) {
+    // d = lowest differing action id; the set holding d is smaller iff the other has an element > d
+    for (int w = 0; w < KW; ++w) {
+        uint64_t diff = x[w] ^ y[w];
+        if (!diff) continue;
+        int b = __builtin_ctzll(diff);
+        bool x_has = (x[w] >> b) & 1ull;
+        const uint64_t *other = x_has ? y : x;
+        bool other_has_more = (b < 63 ? (other[w] >> (b + 1)) != 0 : false);
+        for (int w2 = w + 1; w2 < KW && !other_has_more; ++w2) other_has_more = other[w2] != 0;
+        // x_has: x < y iff y continues; else y has d: x < y iff x does NOT continue (x is a proper prefix)
+        return x_has ? other_has_more : !other_has_more;
+    }
+    return false;
+}
+
+int azd_c21_modify_roots(azd_engine *e, uint64_t seed, uint64_t epoch, int kmin, int kmax, uint8_t *parents_out,
+                         uint64_t *permitted_out) {
+    if (!e || !parents_out || !permitted_out || !e->initialised) return AZD_ERR_INVALID_ARGUMENT;
+    AZD_HIP(hipSetDevice(e->cfg.device));
+    AZD_HIP(hipStreamSynchronize(e->stream));
+    const azd::Arenas &a = e->a;
+    const int B = a.B, KW = a.KW, n = a.n;
+    std::vector<uint32_t> n_nodes((size_t)B);
+    AZD_HIP(hipMemcpy(n_nodes.data(), a.n_nodes, (size_t)B * 4, hipMemcpyDeviceToHost));
+    std::vector<uint8_t> rp((size_t)B * azd::PARENTS_STRIDE);
+    std::vector<uint64_t> rm((size_t)B * KW);
+    AZD_HIP(hipMemcpy(rp.data(), a.root_parents, rp.size(), hipMemcpyDeviceToHost));
+    AZD_HIP(hipMemcpy(rm.data(), a.root_perm, rm.size() * 8, hipMemcpyDeviceToHost));
+    uint32_t max_nodes = 0;
+    for (uint32_t v : n_nodes) max_nodes = std::max(max_nodes, v);
+    std::vector<azd::NodeRec> nodes((size_t)max_nodes);
+    std::vector<uint64_t> keys((size_t)max_nodes * KW);
+    const uint64_t domain = azd::DOMAIN_RESET ^ (epoch << 32);
+    // (parent, child) of an action id
+    auto act = [&](uint8_t *par, uint64_t *perm, int aid) {
+        int c = 2;
+        while (c * (c + 1) / 2 - 1 <= aid) ++c;
+        int p = aid - (c * (c - 1) / 2 - 1);
+        par[c] = (uint8_t)p;
+        for (int u = 0; u < c; ++u) {
+            int id = c * (c - 1) / 2 + u - 1;
+            perm[id >> 6] &= ~(1ull << (id & 63));
+        }
+    };
+    std::vector<uint32_t> keep;
+    for (int i = 0; i < B; ++i) {
+        const uint64_t agent = e->cfg.first_agent + (uint64_t)i;
+        const uint32_t nn = n_nodes[(size_t)i];
+        AZD_HIP(hipMemcpy(nodes.data(), a.nodes + (size_t)i * a.node_cap, (size_t)nn * sizeof(azd::NodeRec), hipMemcpyDeviceToHost));
+        AZD_HIP(hipMemcpy(keys.data(), a.keys + (size_t)i * a.node_cap * KW, (size_t)nn * KW * 8, hipMemcpyDeviceToHost));
+        uint8_t par[azd::PARENTS_STRIDE];
+        uint64_t perm[azd::MAX_KW] = {0, 0, 0, 0};
+        memcpy(par, &rp[(size_t)i * azd::PARENTS_STRIDE], azd::PARENTS_STRIDE);
+        for (int w = 0; w < KW; ++w) perm[w] = rm[(size_t)i * KW + w];
+        uint8_t *po = parents_out + (size_t)i * n;
+        uint64_t *mo = permitted_out + (size_t)i * KW;
+        const float c_root = nodes[0].c, c_root_star = nodes[0].c_star;
+        const uint64_t r0 = azd::stream_key(seed, domain, agent, 0), r1 = azd::stream_key(seed, domain, agent, 1);
+        int k_new;
+        keep.clear();
+        if (c_root == c_root_star) {
+            int kcur = 0;
+            for (int w = 0; w < KW; ++w) kcur += __builtin_popcountll(perm[w]);
+            if (kcur == kmax) {
+                int k = kmin + (int)azd::draw_below(r1, (uint32_t)(kmax - kmin + 1));
+                azd::c21_fresh_root(seed, domain, agent, n, k, po, mo);
+                continue;
+            }
+            for (uint32_t v = 0; v < nn; ++v)
+                if (nodes[v].c == c_root) keep.push_back(v);
+            k_new = kcur + (int)azd::draw_below(r1, (uint32_t)(kmax - kcur + 1));
+        } else {
+            const float thr = (c_root + 3.0f * c_root_star) / 4.0f;
+            for (uint32_t v = 0; v < nn; ++v)
+                if (nodes[v].c <= thr) keep.push_back(v);
+            k_new = kmin + (int)azd::draw_below(r1, (uint32_t)(kmax - kmin + 1));
+        }
+        const uint32_t r = azd::draw_below(r0, (uint32_t)keep.size());
+        std::nth_element(keep.begin(), keep.begin() + r, keep.end(), [&](uint32_t x, uint32_t y) {
+            return key_less(&keys[(size_t)x * KW], &keys[(size_t)y * KW], KW);
+        });
+        const uint64_t *key = &keys[(size_t)keep[r] * KW];
+        for (int w = 0; w < KW; ++w) {
+            uint64_t bits = key[w];
+            while (bits) {
+                int b = __builtin_ctzll(bits);
+                bits &= bits - 1;
+                act(par, perm, w * 64 + b);
+            }
+        }
+        memcpy(po, par, (size_t)n);
+        azd::c21_shuffle_permitted(seed, domain, agent, n, k_new, mo);
+    }
+    return AZD_OK;
+}
+
+} // extern "C"

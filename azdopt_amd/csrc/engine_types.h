@@ -1,0 +1,132 @@
+// engine_types.h -- device data layout shared by the tree kernels and the host engine.
+//
+// HBM layout (DESIGN.md "Data layout"): every tree owns a fixed-capacity slice of
+// five tree-major arenas.  Records are sized to the 16-B-per-lane vector-load
+// sweet spot of gfx950: a node is two dwordx4, an arc and a prediction one each.
+//
+//   nodes  [B][node_cap]       NodeRec  32 B   StateWeight (tree/state_weight.rs:4-10) + in-list head
+//   keys   [B][node_cap][KW]   u64             ActionSet of the node as a bit mask (path/set.rs:6-9)
+//   arcs   [B][arc_cap]        ArcRec   16 B   petgraph edge: endpoints, ActionWeight.prediction_pos, next-in
+//   preds  [B][pred_cap]       PredRec  16 B   ActionPrediction (tree/arc_weight.rs:11-16) + child node
+//   ht     [B][ht_cap]         u32             open-addressing transposition table over `keys`
+//                                              (stands in for BTreeMap<P, NodeIndex>, tree/mod.rs:29)
+#pragma once
+#include <stdint.h>
+
+namespace azd {
+
+constexpr uint32_t NONE = 0xFFFFFFFFu;
+constexpr int PARENTS_STRIDE = 32; // bytes per packed parents row on the device
+constexpr int MAX_N = 24;
+constexpr int MAX_KW = 4;
+constexpr int PRED_CHUNKS = 2;               // a node holds at most 64*PRED_CHUNKS legal actions
+constexpr int MAX_NODE_ACTIONS = 64 * PRED_CHUNKS;
+constexpr int FRONTIER_CAP = 256;            // LDS-staged cascade frontier per tree
+constexpr int MAX_TOL = 32;
+constexpr int NUM_COUNTERS = 16;
+
+struct __attribute__((aligned(16))) NodeRec {
+    float c;            // evaluate(cost(state))
+    float c_star;       // best eval seen at or below
+    uint32_t n_t;
+    uint32_t exhausted; // exhausted_children
+    uint32_t act_begin; // actions: Range<u32> into preds
+    uint32_t act_end;
+    uint32_t first_in;  // head of the incoming-arc list (newest first), NONE if empty
+    uint32_t pad;
+};
+static_assert(sizeof(NodeRec) == 32, "NodeRec must be 32 B");
+
+struct __attribute__((aligned(16))) ArcRec {
+    uint32_t src, dst;
+    uint32_t pp;      // ActionWeight.prediction_pos
+    uint32_t next_in; // next arc into dst (older), NONE at the tail
+};
+static_assert(sizeof(ArcRec) == 16, "ArcRec must be 16 B");
+
+struct __attribute__((aligned(16))) PredRec {
+    uint32_t a_id;
+    float g;        // g_theta_sa
+    uint32_t arc;   // edge_id: Option<EdgeIndex>, NONE while unexpanded
+    uint32_t child; // target node of `arc` (saves the arcs[] hop during selection)
+};
+static_assert(sizeof(PredRec) == 16, "PredRec must be 16 B");
+
+// flags[agent] bits
+enum : uint32_t {
+    FLAG_NODE_CAP = 1u << 0,
+    FLAG_ARC_CAP = 1u << 1,
+    FLAG_PRED_CAP = 1u << 2,
+    FLAG_FRONTIER_CAP = 1u << 3,
+    FLAG_HT_FULL = 1u << 4,
+    FLAG_UNREACHABLE = 1u << 5,
+    FLAG_NODE_ACTIONS = 1u << 6,
+    FLAG_LOOP_GUARD = 1u << 7,
+};
+
+struct ArgminRec { // device copy of azd_argmin
+    uint8_t parents[32];
+    uint64_t permitted[4];
+    double lambda_1;
+    int32_t matching_size;
+    int32_t matching[32];
+    float eval;
+    int32_t agent;
+    uint32_t node;
+};
+
+struct StatusRec { // small device block copied back after every host-visible call
+    unsigned long long improved;   // k_argmin calls that improved the argmin
+    unsigned long long expansions; // sum over agents and calls (metric numerator)
+    unsigned long long failed;     // agents with a non-zero flag
+    unsigned long long pad;
+};
+
+struct Arenas {
+    NodeRec *nodes;
+    uint64_t *keys;
+    ArcRec *arcs;
+    PredRec *preds;
+    uint32_t *ht;
+    uint32_t node_cap, arc_cap, pred_cap, ht_cap; // ht_cap is a power of two >= 128
+    // per agent
+    uint8_t *root_parents;  // [B][PARENTS_STRIDE]
+    uint64_t *root_perm;    // [B][KW]
+    uint8_t *cur_parents;
+    uint64_t *cur_perm;
+    uint64_t *cur_path;
+    double *cur_lambda;
+    int32_t *cur_mu;
+    uint32_t *state_pos;
+    uint32_t *n_nodes, *n_arcs, *n_preds;
+    uint32_t *flags;
+    float *cand_c;          // first-min eval over nodes created since the last argmin inspection
+    uint32_t *cand_node;
+    unsigned long long *counters; // [B][NUM_COUNTERS]
+    float *state_vecs;      // [B][S]
+    float *h_theta;         // [B][A]
+    float *obs;             // [B][A]
+    float *weights;         // [B][A]
+    ArgminRec *argmin;
+    StatusRec *status;
+    int n, A, S, KW, B;
+    float eval_slope;       // squish slope 1/(C_UPPER - C_LOWER), 04-c21-tree.rs:58-74
+};
+
+struct TolTable {
+    uint32_t tol[MAX_TOL];
+    int n_tol;
+    uint32_t tol_default;
+};
+
+// kernel launchers (tree_kernels.hip); all asynchronous on `stream`
+void launch_init_roots(const Arenas &a, const uint8_t *d_parents, const uint64_t *d_permitted, void *stream);
+void launch_add_actions(const Arenas &a, int root_mode, void *stream);
+void launch_rollout(const Arenas &a, const TolTable &tol, void *stream);
+void launch_argmin(const Arenas &a, int init_mode, void *stream);
+void launch_observe(const Arenas &a, uint32_t n_obs_tol, void *stream);
+void launch_hash_predictions(float *d_out, int batch, int action_dim, uint64_t seed, uint64_t first_agent,
+                             uint64_t call, void *stream);
+void launch_probe_math(const float *d_in, float *d_out, int n, void *stream); // sqrtf / sub parity probe (tests)
+
+} // namespace azd

@@ -1,0 +1,48 @@
+// evaluator.h -- device-side NablaModel (az-discrete-opt/src/nabla/model/mod.rs:4-8)
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include <string>
+
+#include "../../include/azdopt_amd.h"
+
+namespace azd {
+
+extern thread_local std::string g_last_error;
+int hip_fail(hipError_t e, const char *what);
+
+#define AZD_HIP(call)                                        \
+    do {                                                     \
+        hipError_t _e = (call);                              \
+        if (_e != hipSuccess) return azd::hip_fail(_e, #call); \
+    } while (0)
+
+} // namespace azd
+
+struct azd_evaluator {
+    int device = 0;
+    int state_dim = 0;
+    int action_dim = 0;
+    uint64_t calls = 0;
+    // staging for the host-pointer entry points
+    float *d_states = nullptr, *d_preds = nullptr, *d_obs = nullptr, *d_w = nullptr;
+    int staged_batch = 0;
+    hipStream_t own_stream = nullptr;
+
+    virtual ~azd_evaluator();
+    // NablaModel::write_predictions on device pointers
+    virtual int write_predictions_dev(int batch, const float *d_s, float *d_p, hipStream_t st) = 0;
+    // NablaModel::update_model on device pointers; *loss is a host float, valid on return
+    virtual int update_model_dev(int batch, const float *d_s, const float *d_o, const float *d_w, float *loss,
+                                 hipStream_t st) = 0;
+    virtual int64_t num_params() { return 0; }
+    virtual int get_params(float *) { return AZD_ERR_UNSUPPORTED; }
+    virtual int set_params(const float *) { return AZD_ERR_UNSUPPORTED; }
+    int ensure_staging(int batch);
+};
+
+namespace azd {
+azd_evaluator *make_mlp_evaluator(int device, int max_batch, int state_dim, int action_dim, const int *hidden,
+                                  int n_hidden, int final_act, const azd_adam_config *adam, uint64_t seed, int *status);
+}

@@ -1,0 +1,424 @@
+// mlp_kernels.hip -- the evaluator: ActionModel (az-discrete-opt/src/nabla/model/dfdx.rs) as an
+// fp32 MLP on the gfx950 matrix cores.
+//
+//   forward   y = act(x W^T + b) per layer     -> one MFMA GEMM launch per layer, bias+activation
+//                                                  fused into the accumulator epilogue
+//   update    w /= sum(w); L = sum w (p - o)^2  -> loss/delta kernel (deterministic two-stage sums),
+//             backward                             dX / dW GEMMs on the same MFMA kernel (ReLU mask fused),
+//             Adam with L2 (04-c21-tree.rs:87-92)  one elementwise kernel over the flat parameter vector
+//
+// v_mfma_f32_32x32x2_f32 computes an exact f32 FMA chain in k order (no reduced precision), so the
+// forward differs from a CPU fp32 reference only by summation order (tests: 2e-5 abs on sigmoid outputs).
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <new>
+#include <vector>
+
+#include "c21_host.h"
+#include "evaluator.h"
+
+namespace azd {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+constexpr int BM = 64, BN = 64, BK = 16;
+constexpr int LDS_LD = BM + 4; // k-major tiles: s[k][i]; +4 keeps the transposing stores off a 4-way conflict
+
+enum { EPI_NONE = 0, EPI_BIAS_ACT = 1, EPI_RELU_MASK = 2 };
+
+// C[M,N] = epi( sum_k A(i,k) B(k,j) ).
+//   A_KC: A(i,k) = A[i*lda + k] (k contiguous) else A[k*lda + i]
+//   B_KC: B(k,j) = B[j*ldb + k] (k contiguous) else B[k*ldb + j]
+// Tiles are staged through LDS k-major so every MFMA operand read is a conflict-free ds_read_b32;
+// 256 threads = 4 waves in a 2x2 grid of 32x32 accumulators (v_mfma_f32_32x32x2_f32).
+template <bool A_KC, bool B_KC>
+__global__ __launch_bounds__(256) void k_gemm(const float *__restrict__ A, int lda, const float *__restrict__ B, int ldb,
+                                              float *__restrict__ C, int ldc, int M, int N, int K, int epi, int act,
+                                              const float *__restrict__ bias, const float *__restrict__ aux, int ldaux) {
+    __shared__ float sA[BK][LDS_LD];
+    __shared__ float sB[BK][LDS_LD];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+
+    for (int k0 = 0; k0 < K; k0 += BK) {
+        // ---- stage A tile: BM x BK
+        if (A_KC) {
+            int i = tid >> 2, kq = (tid & 3) * 4; // 64 rows x 4 quads
+            int gi = m0 + i, gk = k0 + kq;
+            float v[4] = {0.f, 0.f, 0.f, 0.f};
+            if (gi < M) {
+                const float *p = A + (size_t)gi * lda + gk;
+                if (gk + 3 < K && ((reinterpret_cast<uintptr_t>(p) & 15) == 0)) {
+                    float4 q = *reinterpret_cast<const float4 *>(p);
+                    v[0] = q.x; v[1] = q.y; v[2] = q.z; v[3] = q.w;
+                } else {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+                        if (gk + j < K) v[j] = p[j];
+                }
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) sA[kq + j][i] = v[j];
+        } else {
+            int kk = tid >> 4, iq = (tid & 15) * 4; // 16 k-rows x 16 quads of i
+            int gk = k0 + kk, gi = m0 + iq;
+            float v[4] = {0.f, 0.f, 0.f, 0.f};
+            if (gk < K) {
+                const float *p = A + (size_t)gk * lda + gi;
+                if (gi + 3 < M && ((reinterpret_cast<uintptr_t>(p) & 15) == 0)) {
+                    float4 q = *reinterpret_cast<const float4 *>(p);
+                    v[0] = q.x; v[1] = q.y; v[2] = q.z; v[3] = q.w;
+                } else {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+                        if (gi + j < M) v[j] = p[j];
+                }
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) sA[kk][iq + j] = v[j];
+        }
+        // ---- stage B tile: BK x BN
+        if (B_KC) {
+            int jn = tid >> 2, kq = (tid & 3) * 4;
+            int gj = n0 + jn, gk = k0 + kq;
+            float v[4] = {0.f, 0.f, 0.f, 0.f};
+            if (gj < N) {
+                const float *p = B + (size_t)gj * ldb + gk;
+                if (gk + 3 < K && ((reinterpret_cast<uintptr_t>(p) & 15) == 0)) {
+                    float4 q = *reinterpret_cast<const float4 *>(p);
+                    v[0] = q.x; v[1] = q.y; v[2] = q.z; v[3] = q.w;
+                } else {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+                        if (gk + j < K) v[j] = p[j];
+                }
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) sB[kq + j][jn] = v[j];
+        } else {
+            int kk = tid >> 4, jq = (tid & 15) * 4;
+            int gk = k0 + kk, gj = n0 + jq;
+            float v[4] = {0.f, 0.f, 0.f, 0.f};
+            if (gk < K) {
+                const float *p = B + (size_t)gk * ldb + gj;
+                if (gj + 3 < N && ((reinterpret_cast<uintptr_t>(p) & 15) == 0)) {
+                    float4 q = *reinterpret_cast<const float4 *>(p);
+                    v[0] = q.x; v[1] = q.y; v[2] = q.z; v[3] = q.w;
+                } else {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+                        if (gj + j < N) v[j] = p[j];
+                }
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) sB[kk][jq + j] = v[j];
+        }
+        __syncthreads();
+        // ---- 8 MFMAs: lane l feeds A[i = l&31][k = l>>5], B[k = l>>5][j = l&31]
+        const int li = lane & 31, lk = lane >> 5;
+#pragma unroll
+        for (int kk = 0; kk < BK; kk += 2) {
+            float a = sA[kk + lk][wm * 32 + li];
+            float b = sB[kk + lk][wn * 32 + li];
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc, 0, 0, 0);
+        }
+        __syncthreads();
+    }
+    // ---- epilogue: C/D layout col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
+    const int col = n0 + wn * 32 + (lane & 31);
+    if (col < N) {
+        float bj = (epi == EPI_BIAS_ACT && bias) ? bias[col] : 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            int row = m0 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+            if (row < M) {
+                float v = acc[r];
+                if (epi == EPI_BIAS_ACT) {
+                    v += bj;
+                    if (act == AZD_ACT_RELU) v = v > 0.f ? v : 0.f;
+                    else if (act == AZD_ACT_SIGMOID) v = 1.0f / (1.0f + expf(-v));
+                } else if (epi == EPI_RELU_MASK) {
+                    v = aux[(size_t)row * ldaux + col] > 0.f ? v : 0.f;
+                }
+                C[(size_t)row * ldc + col] = v;
+            }
+        }
+    }
+}
+
+// ---- loss: weight_sum (dfdx.rs:106), then delta = dL/dz of the head and per-block loss partials
+__global__ void k_block_sum(const float *__restrict__ x, size_t n, float *__restrict__ partial) {
+    __shared__ float s[256];
+    float acc = 0.f;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) acc += x[i];
+    s[threadIdx.x] = acc;
+    __syncthreads();
+    for (int off = 128; off > 0; off >>= 1) {
+        if ((int)threadIdx.x < off) s[threadIdx.x] += s[threadIdx.x + off];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) partial[blockIdx.x] = s[0];
+}
+__global__ void k_final_sum(const float *__restrict__ partial, int n, float *__restrict__ out) {
+    __shared__ float s[256];
+    float acc = 0.f;
+    for (int i = threadIdx.x; i < n; i += blockDim.x) acc += partial[i];
+    s[threadIdx.x] = acc;
+    __syncthreads();
+    for (int off = 128; off > 0; off >>= 1) {
+        if ((int)threadIdx.x < off) s[threadIdx.x] += s[threadIdx.x + off];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) *out = s[0];
+}
+// dfdx.rs:110,118-123: w~ = w / weight_sum; L = sum w~ (p - o)^2; d = dL/dz through the head activation
+__global__ void k_loss_delta(const float *__restrict__ pred, const float *__restrict__ obs, const float *__restrict__ w,
+                             const float *__restrict__ wsum, size_t n, int act, float *__restrict__ delta,
+                             float *__restrict__ partial) {
+    __shared__ float s[256];
+    const float ws = *wsum;
+    float acc = 0.f;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        float wt = w[i] / ws;
+        float p = pred[i];
+        float d = p - obs[i];
+        acc += wt * d * d;
+        float dp = 2.0f * wt * d;
+        if (act == AZD_ACT_SIGMOID) dp *= p * (1.0f - p);
+        else if (act == AZD_ACT_RELU) dp = p > 0.f ? dp : 0.f;
+        delta[i] = dp;
+    }
+    s[threadIdx.x] = acc;
+    __syncthreads();
+    for (int off = 128; off > 0; off >>= 1) {
+        if ((int)threadIdx.x < off) s[threadIdx.x] += s[threadIdx.x + off];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) partial[blockIdx.x] = s[0];
+}
+// db[j] = sum_i dZ[i][j]
+__global__ void k_col_sum(const float *__restrict__ dz, int M, int N, float *__restrict__ out) {
+    int j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= N) return;
+    float acc = 0.f;
+    for (int i = 0; i < M; ++i) acc += dz[(size_t)i * N + j];
+    out[j] = acc;
+}
+// dfdx Adam with WeightDecay::L2: g += wd p; m, v; bias-corrected; p -= lr m^ / (sqrt(v^) + eps)
+__global__ void k_adam(float *__restrict__ p, const float *__restrict__ g, float *__restrict__ m, float *__restrict__ v,
+                       size_t n, float lr, float b1, float b2, float eps, float l2, float bc1, float bc2) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    float gi = g[i] + l2 * p[i];
+    float mi = b1 * m[i] + (1.0f - b1) * gi;
+    float vi = b2 * v[i] + (1.0f - b2) * gi * gi;
+    m[i] = mi;
+    v[i] = vi;
+    float mh = mi / bc1, vh = vi / bc2;
+    p[i] -= lr * mh / (sqrtf(vh) + eps);
+}
+
+template <bool A_KC, bool B_KC>
+static void gemm(hipStream_t st, const float *A, int lda, const float *B, int ldb, float *C, int ldc, int M, int N, int K,
+                 int epi, int act, const float *bias, const float *aux, int ldaux) {
+    dim3 grid((N + BN - 1) / BN, (M + BM - 1) / BM);
+    k_gemm<A_KC, B_KC><<<grid, dim3(256), 0, st>>>(A, lda, B, ldb, C, ldc, M, N, K, epi, act, bias, aux, ldaux);
+}
+
+struct MlpEvaluator : azd_evaluator {
+    int L = 0;
+    std::vector<int> dims; // L+1
+    int final_act = AZD_ACT_SIGMOID;
+    azd_adam_config adam{};
+    int max_batch = 0;
+    int t = 0;
+    int64_t n_params = 0;
+    std::vector<int64_t> w_off, b_off;
+    float *d_params = nullptr, *d_grads = nullptr, *d_m = nullptr, *d_v = nullptr;
+    std::vector<float *> d_act; // d_act[l], l = 1..L-1 hidden outputs (max_batch x dims[l]); [0] and [L] are caller buffers
+    float *d_pred_train = nullptr;
+    float *d_delta_a = nullptr, *d_delta_b = nullptr; // ping-pong deltas (max_batch x max_dim)
+    float *d_partial = nullptr, *d_scalars = nullptr; // [0] wsum [1] loss
+    float *h_scalars = nullptr;
+    int cap_batch = 0;
+
+    ~MlpEvaluator() override {
+        (void)hipSetDevice(device);
+        for (float *p : {d_params, d_grads, d_m, d_v, d_pred_train, d_delta_a, d_delta_b, d_partial, d_scalars})
+            if (p) (void)hipFree(p);
+        for (float *p : d_act)
+            if (p) (void)hipFree(p);
+        if (h_scalars) (void)hipHostFree(h_scalars);
+    }
+
+    int ensure_batch(int batch) {
+        if (batch <= cap_batch) return AZD_OK;
+        for (float *&p : d_act) {
+            if (p) (void)hipFree(p);
+            p = nullptr;
+        }
+        for (float **pp : {&d_pred_train, &d_delta_a, &d_delta_b}) {
+            if (*pp) (void)hipFree(*pp);
+            *pp = nullptr;
+        }
+        int maxd = 0;
+        for (int d : dims) maxd = d > maxd ? d : maxd;
+        d_act.assign((size_t)L + 1, nullptr);
+        for (int l = 1; l < L; ++l) AZD_HIP(hipMalloc(&d_act[(size_t)l], (size_t)batch * dims[(size_t)l] * 4));
+        AZD_HIP(hipMalloc(&d_pred_train, (size_t)batch * dims[(size_t)L] * 4));
+        AZD_HIP(hipMalloc(&d_delta_a, (size_t)batch * maxd * 4));
+        AZD_HIP(hipMalloc(&d_delta_b, (size_t)batch * maxd * 4));
+        cap_batch = batch;
+        return AZD_OK;
+    }
+
+    int forward(int batch, const float *d_s, float *d_p, hipStream_t st) {
+        const float *x = d_s;
+        for (int l = 0; l < L; ++l) {
+            float *y = (l == L - 1) ? d_p : d_act[(size_t)l + 1];
+            int act = (l == L - 1) ? final_act : AZD_ACT_RELU;
+            gemm<true, true>(st, x, dims[(size_t)l], d_params + w_off[(size_t)l], dims[(size_t)l], y, dims[(size_t)l + 1], batch,
+                             dims[(size_t)l + 1], dims[(size_t)l], EPI_BIAS_ACT, act, d_params + b_off[(size_t)l], nullptr, 0);
+            x = y;
+        }
+        AZD_HIP(hipGetLastError());
+        return AZD_OK;
+    }
+
+    // dfdx.rs:69-84
+    int write_predictions_dev(int batch, const float *d_s, float *d_p, hipStream_t st) override {
+        AZD_HIP(hipSetDevice(device));
+        int s = ensure_batch(batch);
+        if (s) return s;
+        calls += 1;
+        return forward(batch, d_s, d_p, st);
+    }
+
+    // dfdx.rs:86-131
+    int update_model_dev(int batch, const float *d_s, const float *d_o, const float *d_w, float *loss, hipStream_t st) override {
+        AZD_HIP(hipSetDevice(device));
+        int s = ensure_batch(batch);
+        if (s) return s;
+        s = forward(batch, d_s, d_pred_train, st);
+        if (s) return s;
+        const int A = dims[(size_t)L];
+        const size_t n = (size_t)batch * A;
+        const int nb = 256;
+        k_block_sum<<<nb, 256, 0, st>>>(d_w, n, d_partial);
+        k_final_sum<<<1, 256, 0, st>>>(d_partial, nb, d_scalars);
+        k_loss_delta<<<nb, 256, 0, st>>>(d_pred_train, d_o, d_w, d_scalars, n, final_act, d_delta_a, d_partial);
+        k_final_sum<<<1, 256, 0, st>>>(d_partial, nb, d_scalars + 1);
+        float *dz = d_delta_a, *dx = d_delta_b;
+        for (int l = L - 1; l >= 0; --l) {
+            const int in = dims[(size_t)l], out = dims[(size_t)l + 1];
+            const float *x = (l == 0) ? d_s : d_act[(size_t)l];
+            // dW[out][in] = dZ^T[out][batch] . X[batch][in]
+            gemm<false, false>(st, dz, out, x, in, d_grads + w_off[(size_t)l], in, out, in, batch, EPI_NONE, 0, nullptr, nullptr, 0);
+            k_col_sum<<<(out + 255) / 256, 256, 0, st>>>(dz, batch, out, d_grads + b_off[(size_t)l]);
+            if (l > 0) {
+                // dX[batch][in] = (dZ[batch][out] . W[out][in]) masked by ReLU'(x)
+                gemm<true, false>(st, dz, out, d_params + w_off[(size_t)l], in, dx, in, batch, in, out, EPI_RELU_MASK, 0, nullptr, x, in);
+                float *tmp = dz;
+                dz = dx;
+                dx = tmp;
+            }
+        }
+        t += 1;
+        float bc1 = 1.0f - std::pow(adam.beta1, (float)t), bc2 = 1.0f - std::pow(adam.beta2, (float)t);
+        k_adam<<<(unsigned)((n_params + 255) / 256), 256, 0, st>>>(d_params, d_grads, d_m, d_v, (size_t)n_params, adam.lr, adam.beta1,
+                                                                  adam.beta2, adam.eps, adam.l2, bc1, bc2);
+        AZD_HIP(hipGetLastError());
+        AZD_HIP(hipMemcpyAsync(h_scalars, d_scalars, 2 * sizeof(float), hipMemcpyDeviceToHost, st));
+        AZD_HIP(hipStreamSynchronize(st));
+        if (loss) *loss = h_scalars[1];
+        return AZD_OK;
+    }
+
+    int64_t num_params() override { return n_params; }
+    int get_params(float *out) override {
+        AZD_HIP(hipSetDevice(device));
+        AZD_HIP(hipDeviceSynchronize());
+        AZD_HIP(hipMemcpy(out, d_params, (size_t)n_params * 4, hipMemcpyDeviceToHost));
+        return AZD_OK;
+    }
+    int set_params(const float *in) override {
+        AZD_HIP(hipSetDevice(device));
+        AZD_HIP(hipDeviceSynchronize());
+        AZD_HIP(hipMemcpy(d_params, in, (size_t)n_params * 4, hipMemcpyHostToDevice));
+        return AZD_OK;
+    }
+};
+
+static int mlp_init(MlpEvaluator *m, uint64_t seed) {
+    AZD_HIP(hipSetDevice(m->device));
+    AZD_HIP(hipMalloc(&m->d_params, (size_t)m->n_params * 4));
+    AZD_HIP(hipMalloc(&m->d_grads, (size_t)m->n_params * 4));
+    AZD_HIP(hipMalloc(&m->d_m, (size_t)m->n_params * 4));
+    AZD_HIP(hipMalloc(&m->d_v, (size_t)m->n_params * 4));
+    AZD_HIP(hipMalloc(&m->d_partial, 256 * 4));
+    AZD_HIP(hipMalloc(&m->d_scalars, 4 * 4));
+    AZD_HIP(hipHostMalloc((void **)&m->h_scalars, 4 * 4));
+    AZD_HIP(hipMemset(m->d_grads, 0, (size_t)m->n_params * 4));
+    AZD_HIP(hipMemset(m->d_m, 0, (size_t)m->n_params * 4));
+    AZD_HIP(hipMemset(m->d_v, 0, (size_t)m->n_params * 4));
+    // dfdx Linear init: weight and bias ~ U(-1/sqrt(in), 1/sqrt(in)) (counter-based draws)
+    std::vector<float> h((size_t)m->n_params);
+    for (int l = 0; l < m->L; ++l) {
+        int in = m->dims[(size_t)l], out = m->dims[(size_t)l + 1];
+        float bound = 1.0f / std::sqrt((float)in);
+        for (int64_t i = 0; i < (int64_t)in * out; ++i) {
+            uint64_t r = stream_key(seed, 0x6d6c7057ull, (uint64_t)l, (uint64_t)i);
+            float u = (float)(r >> 40) * (1.0f / 16777216.0f);
+            h[(size_t)(m->w_off[(size_t)l] + i)] = (2.0f * u - 1.0f) * bound;
+        }
+        for (int i = 0; i < out; ++i) {
+            uint64_t r = stream_key(seed, 0x6d6c7062ull, (uint64_t)l, (uint64_t)i);
+            float u = (float)(r >> 40) * (1.0f / 16777216.0f);
+            h[(size_t)(m->b_off[(size_t)l] + i)] = (2.0f * u - 1.0f) * bound;
+        }
+    }
+    AZD_HIP(hipMemcpy(m->d_params, h.data(), h.size() * 4, hipMemcpyHostToDevice));
+    return m->ensure_batch(m->max_batch);
+}
+
+azd_evaluator *make_mlp_evaluator(int device, int max_batch, int state_dim, int action_dim, const int *hidden, int n_hidden,
+                                  int final_act, const azd_adam_config *adam, uint64_t seed, int *status) {
+    MlpEvaluator *m = new (std::nothrow) MlpEvaluator();
+    if (!m) {
+        *status = AZD_ERR_OUT_OF_MEMORY;
+        return nullptr;
+    }
+    m->device = device;
+    m->state_dim = state_dim;
+    m->action_dim = action_dim;
+    m->L = n_hidden + 1;
+    m->dims.push_back(state_dim);
+    for (int i = 0; i < n_hidden; ++i) m->dims.push_back(hidden[i]);
+    m->dims.push_back(action_dim);
+    m->final_act = final_act;
+    m->adam = *adam;
+    m->max_batch = max_batch;
+    int64_t off = 0;
+    for (int l = 0; l < m->L; ++l) {
+        m->w_off.push_back(off);
+        off += (int64_t)m->dims[(size_t)l] * m->dims[(size_t)l + 1];
+        m->b_off.push_back(off);
+        off += m->dims[(size_t)l + 1];
+    }
+    m->n_params = off;
+    int st = mlp_init(m, seed);
+    if (st) {
+        delete m;
+        *status = st;
+        return nullptr;
+    }
+    *status = AZD_OK;
+    return m;
+}
+
+} // namespace azd

@@ -1,0 +1,992 @@
+// tree_kernels.hip -- the data-parallel tree-search step on gfx950.
+//
+// One 64-lane wavefront owns one agent (= one SearchTree + its state).  Control
+// flow is wave-uniform; lanes parallelise the per-node work:
+//   * lanes <-> the node's action predictions (one dwordx4 PredRec per lane),
+//   * lanes <-> children for the gather of their 32-B NodeRec,
+//   * wave reductions (shuffle butterflies over 64 lanes) for the child argmin /
+//     curiosity argmax with the reference's first-min / last-max tie rules,
+//   * lanes <-> 64 probe slots of the transposition table,
+//   * lanes <-> 64 trial points of the lambda_1 multisection,
+//   * ballot + prefix popcount to append the legal actions of a new node.
+// Built with -ffp-contract=off: every f32/f64 operation below is a single IEEE
+// operation so results are bit-identical to the CPU oracle.
+//
+// Reference semantics (file:line relative to the reference root) are cited at
+// each device function.
+#include <hip/hip_runtime.h>
+
+#include "engine_types.h"
+
+namespace azd {
+
+#define LANE ((int)(threadIdx.x & 63))
+// Intra-wave LDS hand-off: a wave's LDS operations complete in issue order, so lanes only need
+// the compiler kept from reordering across this point plus the lgkmcnt drain the fences emit.
+// (No s_barrier: one wave per agent, and k_argmin's tail runs on a single wave of a larger block.)
+#define WAVE_SYNC()                                              \
+    do {                                                         \
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");   \
+        __builtin_amdgcn_wave_barrier();                         \
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");   \
+    } while (0)
+
+// ---------------------------------------------------------------- small helpers
+__device__ __forceinline__ uint32_t ordf(float f) {
+    // order-preserving map f32 -> u32 (after folding -0.0 into +0.0, as partial_cmp treats them equal)
+    f = f + 0.0f;
+    uint32_t u = __float_as_uint(f);
+    return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+__device__ __forceinline__ uint64_t wave_min_u64(uint64_t v) {
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) {
+        uint64_t o = __shfl_xor(v, off, 64);
+        v = o < v ? o : v;
+    }
+    return v;
+}
+__device__ __forceinline__ uint64_t wave_max_u64(uint64_t v) {
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) {
+        uint64_t o = __shfl_xor(v, off, 64);
+        v = o > v ? o : v;
+    }
+    return v;
+}
+__device__ __forceinline__ uint32_t wave_max_u32(uint32_t v) {
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) {
+        uint32_t o = __shfl_xor(v, off, 64);
+        v = o > v ? o : v;
+    }
+    return v;
+}
+__device__ __forceinline__ int first_lane(uint64_t mask) { return __ffsll((unsigned long long)mask) - 1; }
+__device__ __forceinline__ uint32_t uni(uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); }
+__device__ __forceinline__ uint64_t uni64(uint64_t v) {
+    uint32_t lo = uni((uint32_t)v), hi = uni((uint32_t)(v >> 32));
+    return ((uint64_t)hi << 32) | lo;
+}
+
+template <int KW>
+__device__ __forceinline__ void clear_bit_range(uint64_t (&m)[KW], int lo, int len) {
+#pragma unroll
+    for (int w = 0; w < KW; ++w) {
+        int a = lo - 64 * w, b = lo + len - 64 * w; // [a, b) within this word
+        a = a < 0 ? 0 : a;
+        b = b > 64 ? 64 : b;
+        if (b > a) {
+            uint64_t bits = (b - a == 64) ? ~0ull : (((1ull << (b - a)) - 1ull) << a);
+            m[w] &= ~bits;
+        }
+    }
+}
+template <int KW>
+__device__ __forceinline__ bool mask_empty(const uint64_t (&m)[KW]) {
+    uint64_t o = 0;
+#pragma unroll
+    for (int w = 0; w < KW; ++w) o |= m[w];
+    return o == 0;
+}
+template <int KW>
+__device__ __forceinline__ int mask_count(const uint64_t (&m)[KW]) {
+    int c = 0;
+#pragma unroll
+    for (int w = 0; w < KW; ++w) c += __popcll(m[w]);
+    return c;
+}
+template <int KW>
+__device__ __forceinline__ uint32_t key_hash(const uint64_t (&k)[KW]) {
+    uint64_t h = 0x9E3779B97F4A7C15ull;
+#pragma unroll
+    for (int w = 0; w < KW; ++w) {
+        h = (h ^ k[w]) * 0xFF51AFD7ED558CCDull;
+        h ^= h >> 32;
+    }
+    return (uint32_t)h;
+}
+
+// ---------------------------------------------------------------- per-wave LDS
+// One block = one wave.  The selection scratch (kids / tmp_arc), the cascade frontier and the
+// lambda_1 accumulators are never live together, so they share the dynamic LDS region
+// (dyn_lds_bytes(n) per block: 8.5 KiB at N = 19, which keeps 16 agents resident per CU).
+struct WaveLds {
+    uint8_t par[PARENTS_STRIDE];     // parents of the agent's current state
+    uint8_t act_parent[256];         // action id -> (parent, child), ordered_edge.rs:40-42
+    uint8_t act_child[256];
+};
+// views of the dynamic region
+extern __shared__ double azd_dyn_lds[];
+__device__ __forceinline__ double *lds_acc() { return azd_dyn_lds; }     // [n-2][64]: acc[v-1][lane], v = 1..n-2
+__device__ __forceinline__ float *lds_kids() { return (float *)azd_dyn_lds; } // [MAX_NODE_ACTIONS] c_star, newest arc first
+__device__ __forceinline__ uint32_t *lds_tmp_arc() { return (uint32_t *)azd_dyn_lds + MAX_NODE_ACTIONS; }
+__device__ __forceinline__ uint32_t *lds_fr_id() { return (uint32_t *)azd_dyn_lds; }                 // [2][FRONTIER_CAP]
+__device__ __forceinline__ uint32_t *lds_fr_x() { return (uint32_t *)azd_dyn_lds + 2 * FRONTIER_CAP; } // [2][FRONTIER_CAP]
+static size_t dyn_lds_bytes(int n) {
+    size_t acc = (size_t)(n - 2) * 64 * sizeof(double);
+    size_t fr = (size_t)4 * FRONTIER_CAP * sizeof(uint32_t);
+    size_t sel = (size_t)2 * MAX_NODE_ACTIONS * sizeof(uint32_t);
+    size_t m = acc > fr ? acc : fr;
+    return m > sel ? m : sel;
+}
+
+// action id -> (parent, child): index(parent, child) = child(child-1)/2 + parent - 1
+// (edge.rs:48-65 colex position minus the skipped edge 0-1, ordered_edge.rs:35-42)
+__device__ __forceinline__ void build_action_table(WaveLds &s, int A) {
+    for (int i = LANE; i < A; i += 64) {
+        int c = 2;
+        while (c * (c + 1) / 2 - 1 <= i) ++c;
+        s.act_child[i] = (uint8_t)c;
+        s.act_parent[i] = (uint8_t)(i - (c * (c - 1) / 2 - 1));
+    }
+}
+
+// bit a set <=> action a is a current parent edge (rooted_tree/mod.rs:60-72)
+template <int KW>
+__device__ __forceinline__ void current_edges(const WaveLds &s, int A, uint64_t (&out)[KW]) {
+#pragma unroll
+    for (int w = 0; w < KW; ++w) {
+        int i = w * 64 + LANE;
+        bool e = (i < A) && (s.par[s.act_child[i]] == s.act_parent[i]);
+        out[w] = __ballot(e);
+    }
+}
+
+// space.rs:56-73 `act`: parents[child] = parent; drop every permitted (u, child), u < child --
+// those ids are the contiguous range [child(child-1)/2 - 1, +child)
+template <int KW>
+__device__ __forceinline__ void do_act(WaveLds &s, uint64_t (&perm)[KW], uint32_t a) {
+    int p = s.act_parent[a], c = s.act_child[a];
+    if (LANE == 0) s.par[c] = (uint8_t)p;
+    clear_bit_range<KW>(perm, c * (c - 1) / 2 - 1, c);
+    WAVE_SYNC();
+}
+
+// lambda_1 cost contract: pivots of the leaf-first LDL^T of xI - A at 64 trial
+// points per round, ten rounds of multisection on [1, N].  ordered_edge.rs:72-82 (faer) stand-in.
+__device__ double lambda1_wave(WaveLds &s, int n) {
+    double lo = 1.0, hi = (double)n;
+    double *acc = lds_acc();
+    for (int round = 0; round < 10; ++round) {
+        double w = (hi - lo) / 65.0;
+        double step = w * (double)(LANE + 1);
+        double x = lo + step;
+        for (int v = 1; v < n - 1; ++v) acc[(v - 1) * 64 + LANE] = 0.0;
+        double acc0 = 0.0;
+        bool ok = true;
+        for (int v = n - 1; v >= 1; --v) {
+            // vertex n-1 is always a leaf (no vertex has a larger index): its accumulator is 0
+            double av = (v == n - 1) ? 0.0 : acc[(v - 1) * 64 + LANE];
+            double d = x - av;
+            if (!(d > 0.0)) ok = false;
+            double inv = 1.0 / d;
+            int p = s.par[v];
+            if (p == 0) acc0 = acc0 + inv;
+            else acc[(p - 1) * 64 + LANE] = acc[(p - 1) * 64 + LANE] + inv;
+        }
+        double d0 = x - acc0;
+        if (!(d0 > 0.0)) ok = false;
+        uint64_t m = __ballot(ok);
+        int first = m ? first_lane(m) : 64;
+        double x_prev = __shfl(x, first > 0 ? first - 1 : 0, 64);
+        double x_first = __shfl(x, first < 64 ? first : 63, 64);
+        double nlo = first > 0 ? x_prev : lo;
+        double nhi = first < 64 ? x_first : hi;
+        lo = nlo;
+        hi = nhi;
+    }
+    return hi;
+}
+
+// ordered_edge.rs:94-124 maximum_matching (leaf stripping), on bit masks.  Returns |matching|;
+// optionally writes the (parent, child) pairs.
+__device__ int matching_wave(const WaveLds &s, int n, int32_t *pairs_out) {
+    uint32_t avail = (n >= 32) ? 0xFFFFFFFFu : ((1u << n) - 1u);
+    int m = 0;
+    for (int guard = 0; guard < 64; ++guard) {
+        uint32_t leaf = avail;
+        for (int i = 1; i < n; ++i)
+            if ((avail >> i) & 1u) leaf &= ~(1u << s.par[i]);
+        for (int i = 1; i < n; ++i) {
+            if ((leaf >> i) & 1u) {
+                avail &= ~(1u << i);
+                int p = s.par[i];
+                if ((avail >> p) & 1u) {
+                    avail &= ~(1u << p);
+                    if (pairs_out && LANE == 0) {
+                        pairs_out[2 * m] = p;
+                        pairs_out[2 * m + 1] = i;
+                    }
+                    ++m;
+                }
+            }
+        }
+        if (__popc(avail) < 2) break;
+    }
+    return m;
+}
+
+// 04-c21-tree.rs:98-102: squish(matching.len() as f32 + lambda_1 as f32)
+__device__ __forceinline__ float c21_eval(float slope, double lambda1, int mu) {
+    float c = (float)mu + (float)lambda1;
+    float x = c - 2.0f;
+    return slope * x;
+}
+
+// space.rs:91-101 write_vec: [0, A) one-hot of current parent edges, [A, 2A) permitted mask
+template <int KW>
+__device__ __forceinline__ void write_state_vec(const WaveLds &s, const uint64_t (&perm)[KW], int A, float *row) {
+    uint64_t cur[KW];
+    current_edges<KW>(s, A, cur);
+#pragma unroll
+    for (int w = 0; w < KW; ++w) {
+        int i = w * 64 + LANE;
+        if (i < A) {
+            row[i] = (float)((cur[w] >> LANE) & 1ull);
+            row[A + i] = (float)((perm[w] >> LANE) & 1ull);
+        }
+    }
+}
+
+// ---------------------------------------------------------------- transposition table
+// Wave-parallel linear probing: 64 consecutive slots per probe, keys compared by the lanes
+// that hit an occupied slot.  Stands in for BTreeMap::get / insert (tree/mod.rs:170,188).
+template <int KW>
+__device__ uint32_t ht_lookup(const uint32_t *ht, uint32_t mask, const uint64_t *keys, const uint64_t (&k)[KW],
+                              uint32_t *ins_slot) {
+    uint32_t h = key_hash<KW>(k) & mask;
+    for (uint32_t probe = 0; probe <= mask; probe += 64) {
+        uint32_t slot = (h + probe + (uint32_t)LANE) & mask;
+        uint32_t nd = ht[slot];
+        bool empty = nd == NONE;
+        bool match = !empty;
+        if (!empty) {
+#pragma unroll
+            for (int w = 0; w < KW; ++w) match = match && (keys[(size_t)nd * KW + w] == k[w]);
+        }
+        uint64_t mm = __ballot(match), me = __ballot(empty);
+        int fm = mm ? first_lane(mm) : 64, fe = me ? first_lane(me) : 64;
+        if (fm < fe) return (uint32_t)__shfl((int)nd, fm, 64);
+        if (fe < 64) {
+            *ins_slot = (h + probe + (uint32_t)fe) & mask;
+            return NONE;
+        }
+    }
+    *ins_slot = NONE;
+    return NONE;
+}
+
+// ---------------------------------------------------------------- per-agent context
+template <int KW>
+struct Agent {
+    NodeRec *nodes;
+    uint64_t *keys;
+    ArcRec *arcs;
+    PredRec *preds;
+    uint32_t *ht;
+    uint32_t n_nodes, n_arcs, n_preds;
+    uint32_t flags;
+    float cand_c;
+    uint32_t cand_node;
+    unsigned long long ctr[NUM_COUNTERS];
+};
+
+__device__ __forceinline__ bool node_active(const NodeRec &r) { return r.act_begin + r.exhausted < r.act_end; }
+
+// empty_transitions.rs:50-87 (old = false) / :89-127 (old = true).  Level-synchronous sweep over
+// the ancestors of arc (src -> dst); with ActionSet keys the DAG is layered (depth = |set|), so a
+// frontier holds one depth only and the order inside a level cannot matter; the in-list order
+// cannot matter either because the merge is (min, +).  The propagated c_t_star never changes
+// along the sweep (every emitted Info carries the value it received), so it is one scalar.
+template <int KW>
+__device__ void cascade(const Arenas &a, Agent<KW> &ag, WaveLds &s, uint32_t src, uint32_t dst, bool old) {
+    NodeRec t = ag.nodes[dst];
+    const uint32_t n_t_target = t.n_t;
+    const float c = t.c_star;
+    uint32_t x0 = old ? (node_active(t) ? 0u : 1u) : 1u;
+    int cur = 0;
+    uint32_t n_cur = 1;
+    if (LANE == 0) {
+        lds_fr_id()[0] = src;
+        lds_fr_x()[0] = x0;
+    }
+    WAVE_SYNC();
+    while (n_cur != 0) {
+        uint32_t n_nxt = 0;
+        const int nxt = cur ^ 1;
+        if (n_cur > ag.ctr[10]) ag.ctr[10] = n_cur;
+        for (uint32_t i = 0; i < n_cur; ++i) {
+            uint32_t u = lds_fr_id()[cur * FRONTIER_CAP + i];
+            uint32_t x = lds_fr_x()[cur * FRONTIER_CAP + i];
+            NodeRec r = ag.nodes[u];
+            r.exhausted += x;
+            if (r.c_star > c) r.c_star = c;
+            else r.n_t += 1;
+            if (old) r.n_t = r.n_t > n_t_target ? r.n_t : n_t_target;
+            if (LANE == 0) {
+                ag.nodes[u].c_star = r.c_star;
+                ag.nodes[u].n_t = r.n_t;
+                ag.nodes[u].exhausted = r.exhausted;
+            }
+            ag.ctr[7] += 1;
+            uint32_t up_x = node_active(r) ? 0u : 1u;
+            uint32_t e = r.first_in;
+            while (e != NONE) {
+                ArcRec ar = ag.arcs[e];
+                uint32_t p = ar.src;
+                int found = -1;
+                for (uint32_t base = 0; base < n_nxt; base += 64) {
+                    uint32_t j = base + (uint32_t)LANE;
+                    bool hit = (j < n_nxt) && (lds_fr_id()[nxt * FRONTIER_CAP + j] == p);
+                    uint64_t m = __ballot(hit);
+                    if (m) {
+                        found = (int)base + first_lane(m);
+                        break;
+                    }
+                }
+                if (found >= 0) {
+                    if (LANE == 0) lds_fr_x()[nxt * FRONTIER_CAP + found] += up_x;
+                } else {
+                    if (n_nxt >= FRONTIER_CAP) {
+                        ag.flags |= FLAG_FRONTIER_CAP;
+                        return;
+                    }
+                    if (LANE == 0) {
+                        lds_fr_id()[nxt * FRONTIER_CAP + n_nxt] = p;
+                        lds_fr_x()[nxt * FRONTIER_CAP + n_nxt] = up_x;
+                    }
+                    n_nxt += 1;
+                }
+                WAVE_SYNC();
+                e = ar.next_in;
+            }
+        }
+        cur = nxt;
+        n_cur = n_nxt;
+    }
+}
+
+// graph_operations.rs:18-30 add_arc (+ petgraph head insertion into dst's in-list)
+template <int KW>
+__device__ __forceinline__ uint32_t add_arc(Agent<KW> &ag, uint32_t src, uint32_t dst, uint32_t pp) {
+    uint32_t e = ag.n_arcs;
+    if (LANE == 0) {
+        ArcRec ar;
+        ar.src = src;
+        ar.dst = dst;
+        ar.pp = pp;
+        ar.next_in = ag.nodes[dst].first_in;
+        ag.arcs[e] = ar;
+        ag.nodes[dst].first_in = e;
+        ag.preds[pp].arc = e;
+        ag.preds[pp].child = dst;
+    }
+    ag.n_arcs = e + 1;
+    return e;
+}
+
+// ---------------------------------------------------------------- kernels
+template <int KW>
+__global__ __launch_bounds__(64) void k_init_roots(Arenas a, const uint8_t *__restrict__ parents,
+                                                   const uint64_t *__restrict__ permitted) {
+    __shared__ WaveLds s;
+    const int t = blockIdx.x;
+    const int n = a.n, A = a.A;
+    build_action_table(s, A);
+    if (LANE < PARENTS_STRIDE) {
+        uint8_t p = LANE < n ? parents[(size_t)t * n + LANE] : 0;
+        s.par[LANE] = p;
+        a.root_parents[(size_t)t * PARENTS_STRIDE + LANE] = p;
+        a.cur_parents[(size_t)t * PARENTS_STRIDE + LANE] = p;
+    }
+    uint64_t perm[KW];
+#pragma unroll
+    for (int w = 0; w < KW; ++w) {
+        perm[w] = permitted[(size_t)t * KW + w];
+        if (LANE == 0) {
+            a.root_perm[(size_t)t * KW + w] = perm[w];
+            a.cur_perm[(size_t)t * KW + w] = perm[w];
+            a.cur_path[(size_t)t * KW + w] = 0;
+        }
+    }
+    WAVE_SYNC();
+    // optimizer/mod.rs:63 costs = space.cost(root)
+    double lam = lambda1_wave(s, n);
+    int mu = matching_wave(s, n, nullptr);
+    float c = c21_eval(a.eval_slope, lam, mu);
+    // SearchTree::clear + add_node(P::new(), StateWeight::new(c)) (optimizer/mod.rs:81-84, :353-356)
+    uint32_t *ht = a.ht + (size_t)t * a.ht_cap;
+    for (uint32_t i = LANE; i < a.ht_cap; i += 64) ht[i] = NONE;
+    WAVE_SYNC();
+    uint64_t zero[KW];
+#pragma unroll
+    for (int w = 0; w < KW; ++w) zero[w] = 0;
+    if (LANE == 0) {
+        NodeRec r;
+        r.c = c; r.c_star = c; r.n_t = 0; r.exhausted = 0; r.act_begin = 0; r.act_end = 0; r.first_in = NONE; r.pad = 0;
+        a.nodes[(size_t)t * a.node_cap] = r;
+#pragma unroll
+        for (int w = 0; w < KW; ++w) a.keys[((size_t)t * a.node_cap) * KW + w] = 0;
+        ht[key_hash<KW>(zero) & (a.ht_cap - 1)] = 0;
+        a.cur_lambda[t] = lam;
+        a.cur_mu[t] = mu;
+        a.state_pos[t] = 0;
+        a.n_nodes[t] = 1;
+        a.n_arcs[t] = 0;
+        a.n_preds[t] = 0;
+        a.flags[t] = 0;
+        a.cand_c[t] = c; // num_inspected_nodes = 0: the root is inspected by the next argmin pass
+        a.cand_node[t] = 0;
+    }
+    write_state_vec<KW>(s, perm, A, a.state_vecs + (size_t)t * a.S);
+}
+
+// graph_operations.rs:32-56 add_actions for the node the agent stands on.
+// root_mode = 1: par_new / par_reset_trees (every agent, node 0); 0: after a roll-out (agents
+// whose path is non-empty, optimizer/mod.rs:186).
+template <int KW>
+__global__ __launch_bounds__(64) void k_add_actions(Arenas a, int root_mode) {
+    __shared__ WaveLds s;
+    const int t = blockIdx.x;
+    if (a.flags[t] != 0) return;
+    uint64_t perm[KW], path[KW];
+#pragma unroll
+    for (int w = 0; w < KW; ++w) {
+        perm[w] = a.cur_perm[(size_t)t * KW + w];
+        path[w] = a.cur_path[(size_t)t * KW + w];
+    }
+    if (!root_mode && mask_empty<KW>(path)) return;
+    const int A = a.A;
+    build_action_table(s, A);
+    if (LANE < PARENTS_STRIDE) s.par[LANE] = a.cur_parents[(size_t)t * PARENTS_STRIDE + LANE];
+    WAVE_SYNC();
+    uint64_t cur[KW], legal[KW];
+    current_edges<KW>(s, A, cur);
+#pragma unroll
+    for (int w = 0; w < KW; ++w) legal[w] = perm[w] & ~cur[w]; // space.rs:75-89 action_data
+    const uint32_t cnt = (uint32_t)mask_count<KW>(legal);
+    const uint32_t begin = a.n_preds[t];
+    uint32_t fl = 0;
+    if (cnt > MAX_NODE_ACTIONS) fl |= FLAG_NODE_ACTIONS;
+    if (begin + cnt > a.pred_cap) fl |= FLAG_PRED_CAP;
+    if (fl) {
+        if (LANE == 0) a.flags[t] = fl;
+        return;
+    }
+    const uint32_t node = a.state_pos[t];
+    NodeRec *nodes = a.nodes + (size_t)t * a.node_cap;
+    PredRec *preds = a.preds + (size_t)t * a.pred_cap;
+    const float c = nodes[node].c;
+    const float *h = a.h_theta + (size_t)t * A;
+    uint32_t before = 0;
+#pragma unroll
+    for (int w = 0; w < KW; ++w) {
+        int i = w * 64 + LANE;
+        if ((legal[w] >> LANE) & 1ull) {
+            uint32_t rank = before + (uint32_t)__popcll(legal[w] & ((1ull << LANE) - 1ull));
+            PredRec p;
+            p.a_id = (uint32_t)i;
+            p.g = c - h[i]; // g_theta_star_sa = c_s - h_theta_sa (04-c21-tree.rs:103)
+            p.arc = NONE;
+            p.child = NONE;
+            preds[begin + rank] = p;
+        }
+        before += (uint32_t)__popcll(legal[w]);
+    }
+    if (LANE == 0) {
+        nodes[node].act_begin = begin;
+        nodes[node].act_end = begin + cnt;
+        a.n_preds[t] = begin + cnt;
+        a.counters[(size_t)t * NUM_COUNTERS + 8] += cnt;
+    }
+}
+
+// tree/mod.rs:113-232 roll_out_episodes for every agent (optimizer/mod.rs:159-174)
+template <int KW>
+__global__ __launch_bounds__(64) void k_rollout(Arenas a, TolTable tol) {
+    __shared__ WaveLds s;
+    const int t = blockIdx.x;
+    if (a.flags[t] != 0) return;
+    const int n = a.n, A = a.A;
+    Agent<KW> ag;
+    ag.nodes = a.nodes + (size_t)t * a.node_cap;
+    ag.keys = a.keys + (size_t)t * a.node_cap * KW;
+    ag.arcs = a.arcs + (size_t)t * a.arc_cap;
+    ag.preds = a.preds + (size_t)t * a.pred_cap;
+    ag.ht = a.ht + (size_t)t * a.ht_cap;
+    ag.n_nodes = a.n_nodes[t];
+    ag.n_arcs = a.n_arcs[t];
+    ag.n_preds = a.n_preds[t];
+    ag.flags = 0;
+    ag.cand_c = a.cand_c[t];
+    ag.cand_node = a.cand_node[t];
+#pragma unroll
+    for (int k = 0; k < NUM_COUNTERS; ++k) ag.ctr[k] = 0;
+
+    build_action_table(s, A);
+    if (LANE < PARENTS_STRIDE) s.par[LANE] = a.cur_parents[(size_t)t * PARENTS_STRIDE + LANE];
+    uint64_t perm[KW], path[KW];
+#pragma unroll
+    for (int w = 0; w < KW; ++w) {
+        perm[w] = a.cur_perm[(size_t)t * KW + w];
+        path[w] = a.cur_path[(size_t)t * KW + w];
+    }
+    uint32_t pos = a.state_pos[t];
+    double cur_lambda = a.cur_lambda[t];
+    int cur_mu = a.cur_mu[t];
+    WAVE_SYNC();
+
+    bool expanded_new = false;
+    for (uint32_t guard = 0;; ++guard) {
+        if (guard > (1u << 22)) {
+            ag.flags |= FLAG_LOOP_GUARD;
+            break;
+        }
+        // ---- next_action (next_action.rs:11-26)
+        const NodeRec rec = ag.nodes[pos];
+        const int depth = mask_count<KW>(path);
+        const uint32_t tl = depth < tol.n_tol ? tol.tol[depth] : tol.tol_default;
+        int kind = 0; // 0 None, 1 Visited, 2 Unvisited
+        uint32_t sel_pp = 0, sel_child = 0, sel_aid = 0;
+        if (node_active(rec)) {
+            const uint32_t nact = rec.act_end - rec.act_begin;
+            ag.ctr[4] += 1;
+            ag.ctr[6] += nact;
+            PredRec p[PRED_CHUNKS];
+            bool valid[PRED_CHUNKS], expd[PRED_CHUNKS];
+            float k_cstar[PRED_CHUNKS];
+            uint64_t rkey[PRED_CHUNKS];
+            uint32_t n_exp = 0;
+            uint64_t exp_mask[PRED_CHUNKS];
+#pragma unroll
+            for (int ch = 0; ch < PRED_CHUNKS; ++ch) {
+                uint32_t idx = (uint32_t)(ch * 64 + LANE);
+                valid[ch] = idx < nact;
+                p[ch].a_id = 0; p[ch].g = 0.f; p[ch].arc = NONE; p[ch].child = NONE;
+                if (valid[ch]) p[ch] = ag.preds[rec.act_begin + idx];
+                expd[ch] = valid[ch] && p[ch].arc != NONE;
+                k_cstar[ch] = 0.f;
+                rkey[ch] = ~0ull;
+                if (expd[ch]) {
+                    NodeRec cr = ag.nodes[p[ch].child];
+                    k_cstar[ch] = cr.c_star;
+                    if (node_active(cr)) rkey[ch] = ((uint64_t)cr.n_t << 32) | (uint64_t)ordf(cr.c_star);
+                }
+                exp_mask[ch] = __ballot(expd[ch]);
+                n_exp += (uint32_t)__popcll(exp_mask[ch]);
+            }
+            ag.ctr[5] += n_exp;
+            // ---- revisit_choice (next_action.rs:28-53): first-min of (n_t, c_t_star) over ACTIVE
+            // children in newest-arc-first order  ==  min key, ties -> largest arc id
+            uint64_t kmin = rkey[0];
+#pragma unroll
+            for (int ch = 1; ch < PRED_CHUNKS; ++ch) kmin = rkey[ch] < kmin ? rkey[ch] : kmin;
+            kmin = wave_min_u64(kmin);
+            bool have_r = kmin != ~0ull;
+            uint32_t r_arc = 0, r_nt = (uint32_t)(kmin >> 32);
+            if (have_r) {
+                uint32_t best = 0;
+#pragma unroll
+                for (int ch = 0; ch < PRED_CHUNKS; ++ch)
+                    if (rkey[ch] == kmin) best = p[ch].arc + 1 > best ? p[ch].arc + 1 : best;
+                r_arc = wave_max_u32(best) - 1;
+            }
+            if (have_r && r_nt < tl) kind = 1;
+            else {
+                // ---- max_curiosity (next_action.rs:55-88)
+                // children's c_t_star (ALL children), newest arc first: rank = #arcs with larger id
+                if (n_exp > 0) {
+                    uint32_t off = 0;
+#pragma unroll
+                    for (int ch = 0; ch < PRED_CHUNKS; ++ch) {
+                        if (expd[ch]) lds_tmp_arc()[off + (uint32_t)__popcll(exp_mask[ch] & ((1ull << LANE) - 1ull))] = p[ch].arc;
+                        off += (uint32_t)__popcll(exp_mask[ch]);
+                    }
+                    WAVE_SYNC();
+#pragma unroll
+                    for (int ch = 0; ch < PRED_CHUNKS; ++ch) {
+                        if (expd[ch]) {
+                            uint32_t rank = 0;
+                            for (uint32_t j = 0; j < n_exp; ++j) rank += lds_tmp_arc()[j] > p[ch].arc ? 1u : 0u;
+                            lds_kids()[rank] = k_cstar[ch];
+                        }
+                    }
+                    WAVE_SYNC();
+                }
+                uint64_t best = 0;
+                bool has_cand = false;
+#pragma unroll
+                for (int ch = 0; ch < PRED_CHUNKS; ++ch) {
+                    if (valid[ch] && !expd[ch]) {
+                        uint32_t idx = (uint32_t)(ch * 64 + LANE);
+                        float v = rec.c - p[ch].g; // c_theta_star
+                        uint64_t key;
+                        if (n_exp == 0) {
+                            // min_by: first minimum  ->  maximise (~ord(v), ~idx)
+                            key = ((uint64_t)(~ordf(v)) << 32) | (uint64_t)(0xFFFFFFFFu - idx);
+                        } else {
+                            float sum = 0.0f; // f32 sum, sequential, newest child first
+                            for (uint32_t j = 0; j < n_exp; ++j) sum = sum + __fsqrt_rn(fabsf(lds_kids()[j] - v));
+                            // max_by: last maximum  ->  maximise (ord(sum), idx)
+                            key = ((uint64_t)ordf(sum) << 32) | (uint64_t)idx;
+                        }
+                        best = (!has_cand || key > best) ? key : best;
+                        has_cand = true;
+                    }
+                }
+                ag.ctr[12] += (unsigned long long)n_exp * (unsigned long long)(nact - n_exp);
+                const bool any_cand = __ballot(has_cand) != 0;
+                best = wave_max_u64(has_cand ? best : 0ull);
+                if (any_cand) {
+                    uint32_t idx = (uint32_t)(best & 0xFFFFFFFFull);
+                    if (n_exp == 0) idx = 0xFFFFFFFFu - idx;
+                    kind = 2;
+                    sel_pp = rec.act_begin + idx;
+                    sel_aid = (uint32_t)__shfl((int)(idx >= 64 ? p[1].a_id : p[0].a_id), (int)(idx & 63u), 64);
+                } else if (have_r) kind = 1;
+            }
+            if (kind == 1) {
+                // locate the chosen arc's prediction
+                uint32_t a_id = 0, child = 0;
+                bool mine = false;
+#pragma unroll
+                for (int ch = 0; ch < PRED_CHUNKS; ++ch)
+                    if (expd[ch] && p[ch].arc == r_arc) { mine = true; a_id = p[ch].a_id; child = p[ch].child; }
+                uint64_t mm = __ballot(mine);
+                int src_lane = first_lane(mm);
+                sel_aid = (uint32_t)__shfl((int)a_id, src_lane, 64);
+                sel_child = (uint32_t)__shfl((int)child, src_lane, 64);
+            }
+        }
+        kind = (int)uni((uint32_t)kind);
+        sel_aid = uni(sel_aid);
+
+        if (kind == 1) { // Visited (tree/mod.rs:139-151)
+            sel_child = uni(sel_child);
+            path[sel_aid >> 6] |= 1ull << (sel_aid & 63u);
+            do_act<KW>(s, perm, sel_aid);
+            pos = sel_child;
+            ag.ctr[3] += 1;
+            continue;
+        }
+        if (kind == 0) { // None (tree/mod.rs:220-229)
+            if (mask_empty<KW>(path)) ag.ctr[9] += 1;
+            else ag.flags |= FLAG_UNREACHABLE;
+            break;
+        }
+        // ---- Unvisited(prediction_pos) (tree/mod.rs:160-218)
+        sel_pp = uni(sel_pp);
+        path[sel_aid >> 6] |= 1ull << (sel_aid & 63u);
+        {
+            uint64_t d = (uint64_t)mask_count<KW>(path);
+            if (d > ag.ctr[11]) ag.ctr[11] = d;
+        }
+        if (ag.n_arcs >= a.arc_cap) {
+            ag.flags |= FLAG_ARC_CAP;
+            break;
+        }
+        uint32_t ins_slot = NONE;
+        uint32_t hit = ht_lookup<KW>(ag.ht, a.ht_cap - 1, ag.keys, path, &ins_slot);
+        hit = uni(hit);
+        bool reset_to_root = false;
+        if (hit != NONE) { // transposition (tree/mod.rs:172-179)
+            add_arc<KW>(ag, pos, hit, sel_pp);
+            WAVE_SYNC();
+            cascade<KW>(a, ag, s, pos, hit, true);
+            ag.ctr[2] += 1;
+            reset_to_root = true;
+        } else { // new node (tree/mod.rs:180-216)
+            ins_slot = uni(ins_slot);
+            if (ag.n_nodes >= a.node_cap) {
+                ag.flags |= FLAG_NODE_CAP;
+                break;
+            }
+            if (ins_slot == NONE) {
+                ag.flags |= FLAG_HT_FULL;
+                break;
+            }
+            do_act<KW>(s, perm, sel_aid);
+            cur_lambda = lambda1_wave(s, n);
+            cur_mu = matching_wave(s, n, nullptr);
+            const float c_as = c21_eval(a.eval_slope, cur_lambda, cur_mu);
+            const uint32_t v = ag.n_nodes;
+            if (LANE == 0) {
+                NodeRec r;
+                r.c = c_as; r.c_star = c_as; r.n_t = 0; r.exhausted = 0; r.act_begin = 0; r.act_end = 0; r.first_in = NONE; r.pad = 0;
+                ag.nodes[v] = r;
+#pragma unroll
+                for (int w = 0; w < KW; ++w) ag.keys[(size_t)v * KW + w] = path[w];
+                ag.ht[ins_slot] = v;
+            }
+            ag.n_nodes = v + 1;
+            if (c_as < ag.cand_c || ag.cand_node == NONE) { // first-min over nodes since last inspection
+                ag.cand_c = c_as;
+                ag.cand_node = v;
+            }
+            WAVE_SYNC();
+            add_arc<KW>(ag, pos, v, sel_pp);
+            WAVE_SYNC();
+            uint64_t cur[KW], legal[KW];
+            current_edges<KW>(s, A, cur);
+#pragma unroll
+            for (int w = 0; w < KW; ++w) legal[w] = perm[w] & ~cur[w];
+            if (mask_empty<KW>(legal)) { // terminal: is_terminal, nabla/space/mod.rs:23-25
+                cascade<KW>(a, ag, s, pos, v, false);
+                ag.ctr[1] += 1;
+                reset_to_root = true;
+            } else {
+                pos = v;
+                ag.ctr[0] += 1;
+                expanded_new = true;
+                break;
+            }
+        }
+        if (ag.flags) break;
+        if (reset_to_root) { // state.clone_from(root); path.clear(); state_pos = root
+            WAVE_SYNC();
+            if (LANE < PARENTS_STRIDE) s.par[LANE] = a.root_parents[(size_t)t * PARENTS_STRIDE + LANE];
+#pragma unroll
+            for (int w = 0; w < KW; ++w) {
+                perm[w] = a.root_perm[(size_t)t * KW + w];
+                path[w] = 0;
+            }
+            pos = 0;
+            WAVE_SYNC();
+        }
+    }
+
+    // ---- write back; optimizer/mod.rs:171-173 write_vec iff the path is non-empty
+    WAVE_SYNC();
+    if (expanded_new) write_state_vec<KW>(s, perm, A, a.state_vecs + (size_t)t * a.S);
+    if (LANE < PARENTS_STRIDE) a.cur_parents[(size_t)t * PARENTS_STRIDE + LANE] = s.par[LANE];
+    if (LANE == 0) {
+#pragma unroll
+        for (int w = 0; w < KW; ++w) {
+            a.cur_perm[(size_t)t * KW + w] = perm[w];
+            a.cur_path[(size_t)t * KW + w] = path[w];
+        }
+        a.state_pos[t] = pos;
+        a.cur_lambda[t] = cur_lambda;
+        a.cur_mu[t] = cur_mu;
+        a.n_nodes[t] = ag.n_nodes;
+        a.n_arcs[t] = ag.n_arcs;
+        a.cand_c[t] = ag.cand_c;
+        a.cand_node[t] = ag.cand_node;
+        if (ag.flags) {
+            a.flags[t] = ag.flags;
+            atomicAdd(&a.status->failed, 1ull);
+        }
+        unsigned long long *ctr = a.counters + (size_t)t * NUM_COUNTERS;
+#pragma unroll
+        for (int k = 0; k < NUM_COUNTERS; ++k) {
+            if (k == 10 || k == 11) ctr[k] = ag.ctr[k] > ctr[k] ? ag.ctr[k] : ctr[k];
+            else if (ag.ctr[k]) ctr[k] += ag.ctr[k];
+        }
+        if (expanded_new) atomicAdd(&a.status->expansions, 1ull);
+    }
+}
+
+
+static_assert(PRED_CHUNKS == 2, "selection code addresses prediction chunks 0 and 1 explicitly");
+
+// optimizer/mod.rs:194-246 par_update_argmmim_data (init_mode = 0) and the argmin of par_new
+// (:92-101, init_mode = 1).  One block: a strided scan over agents for the lexicographic min of
+// (c, agent) among candidates with c < best (strict; cross-tree ties -> lowest agent, which the
+// reference leaves to rayon), then wave 0 replays the winner's ActionSet from its root and
+// recomputes the cost (:226-241).
+template <int KW>
+__global__ __launch_bounds__(1024) void k_argmin(Arenas a, int init_mode) {
+    __shared__ unsigned long long s_best[17];
+    __shared__ WaveLds s;
+    const int tid = threadIdx.x;
+    const float best_eval = init_mode ? __int_as_float(0x7f800000) : a.argmin->eval;
+    unsigned long long mine = ~0ull;
+    for (int t = tid; t < a.B; t += blockDim.x) {
+        uint32_t node = a.cand_node[t];
+        float c = a.cand_c[t];
+        if (node != NONE && a.flags[t] == 0 && c < best_eval) {
+            unsigned long long key = ((unsigned long long)ordf(c) << 32) | (unsigned long long)(uint32_t)t;
+            mine = key < mine ? key : mine;
+        }
+    }
+    mine = wave_min_u64(mine);
+    if ((tid & 63) == 0) s_best[tid >> 6] = mine;
+    __syncthreads();
+    if (tid < 64) {
+        unsigned long long v = tid < (int)(blockDim.x >> 6) ? s_best[tid] : ~0ull;
+        v = wave_min_u64(v);
+        if (tid == 0) s_best[16] = v;
+    }
+    __syncthreads();
+    const unsigned long long win = s_best[16];
+    uint32_t win_node = NONE;
+    int wt = -1;
+    if (win != ~0ull) {
+        wt = (int)(win & 0xFFFFFFFFull);
+        win_node = a.cand_node[wt];
+    }
+    __syncthreads();
+    for (int t = tid; t < a.B; t += blockDim.x) a.cand_node[t] = NONE; // num_inspected_nodes = nodes.len()
+    if (tid >= 64 || wt < 0) return;
+    // ---- single wave from here on (WAVE_SYNC only)
+    const int n = a.n, A = a.A;
+    build_action_table(s, A);
+    if (LANE < PARENTS_STRIDE) s.par[LANE] = a.root_parents[(size_t)wt * PARENTS_STRIDE + LANE];
+    uint64_t perm[KW], key[KW];
+#pragma unroll
+    for (int w = 0; w < KW; ++w) {
+        perm[w] = a.root_perm[(size_t)wt * KW + w];
+        key[w] = a.keys[((size_t)wt * a.node_cap + win_node) * KW + w];
+    }
+    WAVE_SYNC();
+#pragma unroll
+    for (int w = 0; w < KW; ++w) {
+        uint64_t bits = key[w];
+        while (bits) {
+            int b = __ffsll((unsigned long long)bits) - 1;
+            bits &= bits - 1;
+            do_act<KW>(s, perm, (uint32_t)(w * 64 + b));
+        }
+    }
+    ArgminRec *out = a.argmin;
+    double lam = lambda1_wave(s, n);
+    int mu = matching_wave(s, n, out->matching);
+    float ev = c21_eval(a.eval_slope, lam, mu);
+    if (LANE < 32) out->parents[LANE] = LANE < n ? s.par[LANE] : 0;
+    if (LANE == 0) {
+#pragma unroll
+        for (int w = 0; w < 4; ++w) out->permitted[w] = 0;
+#pragma unroll
+        for (int w = 0; w < KW; ++w) out->permitted[w] = perm[w];
+        out->lambda_1 = lam;
+        out->matching_size = mu;
+        out->eval = ev;
+        out->agent = wt;
+        out->node = win_node;
+        if (!init_mode) atomicAdd(&a.status->improved, 1ull);
+    }
+}
+
+// optimizer/mod.rs:262-278: state_vecs <- root vectors; obs/weights zeroed then filled by
+// SearchTree::write_observations (tree/mod.rs:242-264); h_sa = c_child* (04-c21-tree.rs:104)
+template <int KW>
+__global__ __launch_bounds__(64) void k_observe(Arenas a, uint32_t n_obs_tol) {
+    __shared__ WaveLds s;
+    const int t = blockIdx.x;
+    const int A = a.A;
+    build_action_table(s, A);
+    if (LANE < PARENTS_STRIDE) s.par[LANE] = a.root_parents[(size_t)t * PARENTS_STRIDE + LANE];
+    uint64_t perm[KW];
+#pragma unroll
+    for (int w = 0; w < KW; ++w) perm[w] = a.root_perm[(size_t)t * KW + w];
+    WAVE_SYNC();
+    write_state_vec<KW>(s, perm, A, a.state_vecs + (size_t)t * a.S);
+    float *obs = a.obs + (size_t)t * A, *wts = a.weights + (size_t)t * A;
+    for (int i = LANE; i < A; i += 64) {
+        obs[i] = 0.f;
+        wts[i] = 0.f;
+    }
+    WAVE_SYNC();
+    const NodeRec *nodes = a.nodes + (size_t)t * a.node_cap;
+    const PredRec *preds = a.preds + (size_t)t * a.pred_cap;
+    const NodeRec root = nodes[0];
+    const uint32_t nact = root.act_end - root.act_begin;
+    for (uint32_t idx = LANE; idx < nact; idx += 64) {
+        PredRec p = preds[root.act_begin + idx];
+        if (p.arc != NONE) {
+            NodeRec cr = nodes[p.child];
+            if (!node_active(cr) || cr.n_t >= n_obs_tol) {
+                obs[p.a_id] = cr.c_star;
+                wts[p.a_id] = 1.0f;
+            }
+        }
+    }
+}
+
+// fixed prediction stream h(agent, call, a) = top 24 bits of key4(seed ^ "pred", agent, call, a) * 2^-24
+__device__ __forceinline__ uint64_t splitmix(uint64_t x) {
+    x += 0x9E3779B97F4A7C15ull;
+    x = (x ^ (x >> 30)) * 0xBF58476D1CE4E5B9ull;
+    x = (x ^ (x >> 27)) * 0x94D049BB133111EBull;
+    return x ^ (x >> 31);
+}
+__global__ void k_hash_predictions(float *out, int batch, int action_dim, uint64_t seed, uint64_t first_agent,
+                                   uint64_t call) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    size_t total = (size_t)batch * action_dim;
+    if (i >= total) return;
+    uint64_t agent = first_agent + i / action_dim, act = i % action_dim;
+    uint64_t r = splitmix(splitmix(splitmix(splitmix(seed ^ 0x70726564ull) ^ agent) ^ call) ^ act);
+    out[i] = (float)(r >> 40) * (1.0f / 16777216.0f);
+}
+
+// parity probe for the two f32 primitives the selection rule depends on:
+// out[2i] = sqrt(|in[2i] - in[2i+1]|) (correctly rounded), out[2i+1] = in[2i] - (in[2i] - in[2i+1])
+__global__ void k_probe_math(const float *in, float *out, int n) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    float x = in[2 * i], y = in[2 * i + 1];
+    out[2 * i] = __fsqrt_rn(fabsf(x - y));
+    float g = x - y;
+    out[2 * i + 1] = x - g;
+}
+
+// ---------------------------------------------------------------- launchers
+#define DISPATCH_KW(KWV, FN, ...)            \
+    switch (KWV) {                           \
+    case 1: FN<1>(__VA_ARGS__); break;       \
+    case 2: FN<2>(__VA_ARGS__); break;       \
+    case 3: FN<3>(__VA_ARGS__); break;       \
+    default: FN<4>(__VA_ARGS__); break;      \
+    }
+
+template <int KW>
+static void l_init_roots(const Arenas &a, const uint8_t *p, const uint64_t *m, hipStream_t st) {
+    k_init_roots<KW><<<dim3(a.B), dim3(64), dyn_lds_bytes(a.n), st>>>(a, p, m);
+}
+template <int KW>
+static void l_add_actions(const Arenas &a, int root_mode, hipStream_t st) {
+    k_add_actions<KW><<<dim3(a.B), dim3(64), dyn_lds_bytes(a.n), st>>>(a, root_mode);
+}
+template <int KW>
+static void l_rollout(const Arenas &a, const TolTable &tol, hipStream_t st) {
+    k_rollout<KW><<<dim3(a.B), dim3(64), dyn_lds_bytes(a.n), st>>>(a, tol);
+}
+template <int KW>
+static void l_argmin(const Arenas &a, int init_mode, hipStream_t st) {
+    k_argmin<KW><<<dim3(1), dim3(1024), dyn_lds_bytes(a.n), st>>>(a, init_mode);
+}
+template <int KW>
+static void l_observe(const Arenas &a, uint32_t tol, hipStream_t st) {
+    k_observe<KW><<<dim3(a.B), dim3(64), dyn_lds_bytes(a.n), st>>>(a, tol);
+}
+
+void launch_init_roots(const Arenas &a, const uint8_t *d_parents, const uint64_t *d_permitted, void *stream) {
+    DISPATCH_KW(a.KW, l_init_roots, a, d_parents, d_permitted, (hipStream_t)stream);
+}
+void launch_add_actions(const Arenas &a, int root_mode, void *stream) {
+    DISPATCH_KW(a.KW, l_add_actions, a, root_mode, (hipStream_t)stream);
+}
+void launch_rollout(const Arenas &a, const TolTable &tol, void *stream) {
+    DISPATCH_KW(a.KW, l_rollout, a, tol, (hipStream_t)stream);
+}
+void launch_argmin(const Arenas &a, int init_mode, void *stream) {
+    DISPATCH_KW(a.KW, l_argmin, a, init_mode, (hipStream_t)stream);
+}
+void launch_observe(const Arenas &a, uint32_t n_obs_tol, void *stream) {
+    DISPATCH_KW(a.KW, l_observe, a, n_obs_tol, (hipStream_t)stream);
+}
+void launch_hash_predictions(float *d_out, int batch, int action_dim, uint64_t seed, uint64_t first_agent,
+                             uint64_t call, void *stream) {
+    size_t total = (size_t)batch * action_dim;
+    int threads = 256;
+    int blocks = (int)((total + threads - 1) / threads);
+    hipLaunchKernelGGL(k_hash_predictions, dim3(blocks), dim3(threads), 0, (hipStream_t)stream, d_out, batch, action_dim,
+                       seed, first_agent, call);
+}
+void launch_probe_math(const float *d_in, float *d_out, int n, void *stream) {
+    hipLaunchKernelGGL(k_probe_math, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, d_in, d_out, n);
+}
+
+} // namespace azd

@@ -1,0 +1,212 @@
+"""NablaOptimizer: the batch driver (az-discrete-opt/src/nabla/optimizer/mod.rs), device resident."""
+import ctypes as C
+
+import numpy as np
+
+from . import _lib
+from .space import ActionSet
+
+
+class ArgminData:
+    """az-discrete-opt/src/log.rs:1-11 for the c21 space"""
+
+    def __init__(self, rec, n, kw):
+        self.state = dict(parents=np.array(rec.parents[:n], np.uint8), permitted=np.array(rec.permitted[:kw], np.uint64))
+        m = rec.matching_size
+        self.cost = dict(lambda_1=rec.lambda_1, matching=[(rec.matching[2 * i], rec.matching[2 * i + 1]) for i in range(m)])
+        self.eval = np.float32(rec.eval)
+        self.agent, self.node = rec.agent, rec.node
+
+
+class TreeView:
+    """Raw arrays of one SearchTree (tree/mod.rs:28-32): nodes, arcs, predictions, keys."""
+    FIELDS = ("c", "c_star", "n_t", "exhausted", "act_begin", "act_end", "keys", "e_src", "e_dst", "e_pp",
+              "p_aid", "p_g", "p_edge")
+
+    def __init__(self, **kw):
+        self.__dict__.update(kw)
+
+
+class NablaOptimizer:
+    """NablaOptimizer<Space, M, P> with P = ActionSet.
+
+    par_new / par_roll_out_episodes / par_update_model / par_reset_trees / argmin_data / get_trees
+    keep the reference's names and meaning (optimizer/mod.rs:30-36,39,121,249,284,361).  The
+    `init_states` and `modify_root` closures stay on the host and hand over packed roots."""
+
+    def __init__(self, space, model, batch, device=0, first_agent=0, node_capacity=0, arc_capacity=0,
+                 prediction_capacity=0, path=ActionSet):
+        if path is not ActionSet or not ActionSet.licensed_for(space):
+            raise TypeError("only ActionSet paths on ActionsNeverRepeat + ActionOrderIndependent spaces are built")
+        self.space, self.model, self.batch, self.first_agent = space, model, batch, first_agent
+        self._L = _lib.lib()
+        cfg = _lib.EngineConfig(space.SPACE_ID, space.n, batch, device, node_capacity, arc_capacity,
+                                prediction_capacity, first_agent)
+        self._h = C.c_void_p()
+        ev = model._h if model is not None else None
+        _lib.check(self._L.azd_engine_create(C.byref(self._h), C.byref(cfg), ev), "azd_engine_create")
+
+    def __del__(self):
+        if getattr(self, "_h", None) and self._h.value:
+            self._L.azd_engine_destroy(self._h)
+            self._h = C.c_void_p()
+
+    @classmethod
+    def par_new(cls, space, init_states, model, batch, **kw):
+        """optimizer/mod.rs:39-118.  `init_states` is either packed roots (parents, permitted)
+        or a callable(count, first_agent) returning them."""
+        opt = cls(space, model, batch, **kw)
+        roots = init_states(batch, opt.first_agent) if callable(init_states) else init_states
+        parents, permitted = opt._roots(*roots)
+        _lib.check(opt._L.azd_engine_par_new(opt._h, _lib.ptr(parents), _lib.ptr(permitted)), "par_new")
+        return opt
+
+    def _roots(self, parents, permitted):
+        parents = np.ascontiguousarray(parents, np.uint8).reshape(self.batch, self.space.n)
+        permitted = np.ascontiguousarray(permitted, np.uint64).reshape(self.batch, self.space.KEY_WORDS)
+        return parents, permitted
+
+    @staticmethod
+    def _tol(n_as_tol):
+        table, default = n_as_tol
+        return np.ascontiguousarray(table, np.uint32), int(default)
+
+    def par_roll_out_episodes(self, n_as_tol, n_calls=1):
+        """optimizer/mod.rs:121-191.  n_as_tol = (table, default) (04-c21-tree.rs:136-138).
+        Returns the number of calls that improved the argmin (0 = ArgminImprovement::Unchanged)."""
+        t, d = self._tol(n_as_tol)
+        imp = C.c_int32()
+        _lib.check(self._L.azd_engine_par_roll_out_episodes(self._h, _lib.ptr(t), len(t), d, n_calls, C.byref(imp)),
+                   "par_roll_out_episodes")
+        return imp.value
+
+    def par_update_model(self, n_obs_tol):
+        """optimizer/mod.rs:249-281"""
+        loss = C.c_float()
+        _lib.check(self._L.azd_engine_par_update_model(self._h, n_obs_tol, C.byref(loss)), "par_update_model")
+        return loss.value
+
+    def par_reset_trees(self, modify_root):
+        """optimizer/mod.rs:284-360.  `modify_root` is packed new roots or a callable(optimizer)
+        returning them (e.g. lambda o: o.c21_modify_roots(seed, epoch))."""
+        roots = modify_root(self) if callable(modify_root) else modify_root
+        parents, permitted = self._roots(*roots)
+        _lib.check(self._L.azd_engine_par_reset_trees(self._h, _lib.ptr(parents), _lib.ptr(permitted)), "par_reset_trees")
+
+    def c21_modify_roots(self, seed, epoch, kmin=None, kmax=None):
+        """The driver's modify_root policy (04-c21-tree.rs:172-206), seeded."""
+        lo, hi = self.space.default_permitted_range()
+        kmin = lo if kmin is None else kmin
+        kmax = hi if kmax is None else kmax
+        parents = np.zeros((self.batch, self.space.n), np.uint8)
+        permitted = np.zeros((self.batch, self.space.KEY_WORDS), np.uint64)
+        _lib.check(self._L.azd_c21_modify_roots(self._h, seed, epoch, kmin, kmax, _lib.ptr(parents), _lib.ptr(permitted)),
+                   "azd_c21_modify_roots")
+        return parents, permitted
+
+    def argmin_data(self):
+        """optimizer/mod.rs:361"""
+        rec = _lib.Argmin()
+        _lib.check(self._L.azd_engine_argmin_data(self._h, C.byref(rec)), "argmin_data")
+        return ArgminData(rec, self.space.n, self.space.KEY_WORDS)
+
+    def get_model_mut(self):
+        return self.model
+
+    # ---- split-phase forms for an external NablaModel (cut at the model call)
+    def par_new_begin(self, parents, permitted):
+        parents, permitted = self._roots(parents, permitted)
+        _lib.check(self._L.azd_engine_par_new_begin(self._h, _lib.ptr(parents), _lib.ptr(permitted)), "par_new_begin")
+
+    def par_new_end(self, h):
+        h = np.ascontiguousarray(h, np.float32)
+        _lib.check(self._L.azd_engine_par_new_end(self._h, _lib.ptr(h)), "par_new_end")
+
+    def roll_out_begin(self, n_as_tol):
+        t, d = self._tol(n_as_tol)
+        _lib.check(self._L.azd_engine_roll_out_begin(self._h, _lib.ptr(t), len(t), d), "roll_out_begin")
+
+    def roll_out_end(self, h):
+        h = np.ascontiguousarray(h, np.float32)
+        imp = C.c_int32()
+        _lib.check(self._L.azd_engine_roll_out_end(self._h, _lib.ptr(h), C.byref(imp)), "roll_out_end")
+        return imp.value
+
+    def reset_begin(self, parents, permitted):
+        parents, permitted = self._roots(parents, permitted)
+        _lib.check(self._L.azd_engine_reset_begin(self._h, _lib.ptr(parents), _lib.ptr(permitted)), "reset_begin")
+
+    def reset_end(self, h):
+        h = np.ascontiguousarray(h, np.float32)
+        _lib.check(self._L.azd_engine_reset_end(self._h, _lib.ptr(h)), "reset_end")
+
+    def observe(self, n_obs_tol):
+        """par_update_model without the model call: (state_vecs, observations, action_weights)"""
+        sv = np.zeros((self.batch, self.space.STATE_DIM), np.float32)
+        obs = np.zeros((self.batch, self.space.ACTION_DIM), np.float32)
+        w = np.zeros((self.batch, self.space.ACTION_DIM), np.float32)
+        _lib.check(self._L.azd_engine_observe(self._h, n_obs_tol, _lib.ptr(sv), _lib.ptr(obs), _lib.ptr(w)), "observe")
+        return sv, obs, w
+
+    def observe_dev(self, n_obs_tol):
+        """device pointers of the training triple (for an all-gather across GPUs)"""
+        a, b, c = C.c_void_p(), C.c_void_p(), C.c_void_p()
+        _lib.check(self._L.azd_engine_observe_dev(self._h, n_obs_tol, C.byref(a), C.byref(b), C.byref(c)), "observe_dev")
+        return a.value, b.value, c.value
+
+    def state_vecs(self):
+        sv = np.zeros((self.batch, self.space.STATE_DIM), np.float32)
+        _lib.check(self._L.azd_engine_read_state_vecs(self._h, _lib.ptr(sv)), "read_state_vecs")
+        return sv
+
+    def predictions(self):
+        h = np.zeros((self.batch, self.space.ACTION_DIM), np.float32)
+        _lib.check(self._L.azd_engine_read_predictions(self._h, _lib.ptr(h)), "read_predictions")
+        return h
+
+    # ---- introspection
+    def tree_sizes(self, agent):
+        a, b, c = C.c_int32(), C.c_int32(), C.c_int32()
+        _lib.check(self._L.azd_engine_tree_sizes(self._h, agent, C.byref(a), C.byref(b), C.byref(c)), "tree_sizes")
+        return a.value, b.value, c.value
+
+    def get_tree(self, agent):
+        nn, ne, npred = self.tree_sizes(agent)
+        kw = self.space.KEY_WORDS
+        t = TreeView(c=np.zeros(nn, np.float32), c_star=np.zeros(nn, np.float32), n_t=np.zeros(nn, np.uint32),
+                     exhausted=np.zeros(nn, np.uint32), act_begin=np.zeros(nn, np.uint32),
+                     act_end=np.zeros(nn, np.uint32), keys=np.zeros((nn, kw), np.uint64),
+                     e_src=np.zeros(ne, np.uint32), e_dst=np.zeros(ne, np.uint32), e_pp=np.zeros(ne, np.uint32),
+                     p_aid=np.zeros(npred, np.uint32), p_g=np.zeros(npred, np.float32), p_edge=np.zeros(npred, np.int32))
+        _lib.check(self._L.azd_engine_export_tree(self._h, agent, *[_lib.ptr(getattr(t, f)) for f in TreeView.FIELDS]),
+                   "export_tree")
+        return t
+
+    def get_trees(self):
+        """optimizer/mod.rs:34-36"""
+        return [self.get_tree(i) for i in range(self.batch)]
+
+    def agent_state(self, agent):
+        parents = np.zeros(self.space.n, np.uint8)
+        permitted = np.zeros(self.space.KEY_WORDS, np.uint64)
+        path = np.zeros(self.space.KEY_WORDS, np.uint64)
+        pos, lam, mu = C.c_uint32(), C.c_double(), C.c_int32()
+        _lib.check(self._L.azd_engine_agent_state(self._h, agent, _lib.ptr(parents), _lib.ptr(permitted), _lib.ptr(path),
+                                                  C.byref(pos), C.byref(lam), C.byref(mu)), "agent_state")
+        return dict(parents=parents, permitted=permitted, path=path, state_pos=pos.value, lambda1=lam.value, matching=mu.value)
+
+    def counters(self):
+        out = np.zeros(_lib.CTR_COUNT, np.uint64)
+        _lib.check(self._L.azd_engine_counters(self._h, _lib.ptr(out)), "counters")
+        return {k: int(out[v]) for k, v in _lib.CTR.items()}
+
+    def set_timing(self, enabled=True):
+        _lib.check(self._L.azd_engine_set_timing(self._h, int(enabled)), "set_timing")
+
+    def timing(self):
+        a, b, n = C.c_double(), C.c_double(), C.c_uint64()
+        _lib.check(self._L.azd_engine_timing(self._h, C.byref(a), C.byref(b), C.byref(n)), "timing")
+        return dict(rollout_ms=a.value, evaluator_ms=b.value, rollout_launches=n.value)
+
+    def stream(self):
+        return self._L.azd_engine_stream(self._h)

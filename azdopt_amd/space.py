@@ -1,0 +1,67 @@
+"""Host-side description of the state/action spaces (the reference's trait surface).
+
+`NablaStateActionSpace` (az-discrete-opt/src/nabla/space/mod.rs:5-39) methods are arbitrary Rust
+in the reference; a device engine needs built-in device implementations, selected by id.  The
+classes here carry the constants and the host-side closures (`init_states`), nothing more."""
+import numpy as np
+
+from . import _lib
+
+
+class ActionsNeverRepeat:
+    """Marker: az-discrete-opt/src/space/axioms.rs:7"""
+
+
+class ActionOrderIndependent:
+    """Marker: az-discrete-opt/src/space/axioms.rs:10"""
+
+
+class ActionSet:
+    """Path encoding keyed by the SET of actions taken (az-discrete-opt/src/path/set.rs:6-37).
+    Licensed only for spaces that are ActionsNeverRepeat + ActionOrderIndependent
+    (space/axioms.rs:16-19).  On the device it is a KW x u64 bit mask per node."""
+
+    @staticmethod
+    def licensed_for(space):
+        return isinstance(space, ActionsNeverRepeat) and isinstance(space, ActionOrderIndependent)
+
+
+class ROTModifyParentsOnce(ActionsNeverRepeat, ActionOrderIndependent):
+    """c21 space: rooted ordered trees on N vertices, each parent may be modified once
+    (graph-state/src/rooted_tree/space.rs:14-125; axioms asserted at :124-125).
+    cost = Conjecture2Dot1Cost {lambda_1, matching}; evaluate = squish(mu + lambda_1)
+    (graph-state/examples/04-c21-tree.rs:58-74,96-105)."""
+
+    SPACE_ID = _lib.SPACE_C21
+
+    def __init__(self, n):
+        self.n = int(n)
+        L = _lib.lib()
+        self.STATE_DIM = L.azd_c21_state_dim(self.n)    # space.rs:46
+        self.ACTION_DIM = L.azd_c21_action_dim(self.n)  # space.rs:48
+        self.KEY_WORDS = L.azd_c21_key_words(self.n)
+
+    def default_permitted_range(self):
+        """04-c21-tree.rs:85: 5..=(ACTION / 2), clamped for tiny N"""
+        hi = max(1, self.ACTION_DIM // 2)
+        return min(5, hi), hi
+
+    def generate_roots(self, seed, count, first_agent=0, epoch=0, kmin=None, kmax=None):
+        """`init_states` of the driver (04-c21-tree.rs:108-112) with a seeded generator.
+        Returns packed roots: parents u8 [count, n], permitted u64 [count, KEY_WORDS]."""
+        lo, hi = self.default_permitted_range()
+        kmin = lo if kmin is None else kmin
+        kmax = hi if kmax is None else kmax
+        parents = np.zeros((count, self.n), np.uint8)
+        permitted = np.zeros((count, self.KEY_WORDS), np.uint64)
+        _lib.check(_lib.lib().azd_c21_generate_roots(seed, epoch, first_agent, count, self.n, kmin, kmax,
+                                                     _lib.ptr(parents), _lib.ptr(permitted)), "azd_c21_generate_roots")
+        return parents, permitted
+
+    @staticmethod
+    def action(index):
+        """(parent, child) of action `index` (ordered_edge.rs:40-42 via edge.rs:55-65)"""
+        c = 2
+        while c * (c + 1) // 2 - 1 <= index:
+            c += 1
+        return index - (c * (c - 1) // 2 - 1), c

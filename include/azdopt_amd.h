@@ -1,0 +1,240 @@
+/*
+ * azdopt_amd.h -- C ABI of the MI355X-native self-play hot path of ariasanovsky/azdopt.
+ *
+ * The reference has no FFI layer; its seams are Rust traits.  Each entry point
+ * below replaces one trait method / pub fn (cited as file:line relative to the
+ * reference root) with the same argument meaning, ownership and layout:
+ *
+ *   evaluator seam   trait NablaModel              az-discrete-opt/src/nabla/model/mod.rs:4-8
+ *                    ActionModel::{new,...}        az-discrete-opt/src/nabla/model/dfdx.rs:36-131
+ *   engine seam      NablaOptimizer pub methods    az-discrete-opt/src/nabla/optimizer/mod.rs:30-36,39,121,249,284,361
+ *   space seam       NablaStateActionSpace         az-discrete-opt/src/nabla/space/mod.rs:5-39
+ *                    (device-resident spaces are built in and selected by id;
+ *                     the trait stays the host-side description)
+ *
+ * Conventions: plain pointers and sizes, no torch types.  Host slices are lent
+ * for the duration of the call (as the Rust `&[f32]` / `&mut [f32]` are) and are
+ * never retained.  All matrices are row-major, agent-major.  Every function
+ * returns an azd_status (0 = OK); nothing aborts the process (the reference
+ * panics with panic='abort', graph-state/Cargo.toml:59,62).
+ *
+ * The library has NO CPU fallback: every compute entry point runs HIP kernels
+ * on a gfx950 device and fails with AZD_ERR_NO_DEVICE when none is present.
+ */
+#ifndef AZDOPT_AMD_H
+#define AZDOPT_AMD_H
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef enum azd_status {
+    AZD_OK = 0,
+    AZD_ERR_INVALID_ARGUMENT = 1,
+    AZD_ERR_NO_DEVICE = 2,
+    AZD_ERR_HIP = 3,
+    AZD_ERR_CAPACITY = 4,      /* a tree arena (nodes / arcs / predictions / frontier) overflowed */
+    AZD_ERR_UNREACHABLE = 5,   /* the reference's unreachable!() at tree/mod.rs:227 */
+    AZD_ERR_NO_EVALUATOR = 6,  /* engine created without an evaluator: use the *_begin/_end pair */
+    AZD_ERR_OUT_OF_MEMORY = 7,
+    AZD_ERR_UNSUPPORTED = 8
+} azd_status;
+
+const char *azd_status_string(int status);
+/* text of the last HIP error seen by the calling thread ("" if none) */
+const char *azd_last_error(void);
+int azd_version(void);
+/* number of visible gfx950 devices (0 on a box without a GPU; never fails) */
+int azd_device_count(void);
+
+/* ------------------------------------------------------------------------- */
+/* Space seam: c21 = ROTModifyParentsOnce<N, Conjecture2Dot1Cost>            */
+/*   graph-state/src/rooted_tree/space.rs:14-125                             */
+/* ------------------------------------------------------------------------- */
+#define AZD_SPACE_C21 1
+#define AZD_C21_MAX_N 24
+int azd_c21_state_dim(int n);  /* (N-1)(N-2)-2     space.rs:46 */
+int azd_c21_action_dim(int n); /* (N-1)(N-2)/2-1   space.rs:48 */
+int azd_c21_key_words(int n);  /* u64 words of an ActionSet bit mask */
+
+/* Host-side `init_states` closure of the driver (04-c21-tree.rs:108-112;
+ * rooted_tree/mod.rs:14-20; modify_parent_once.rs:14-25) with a seeded,
+ * counter-based generator instead of thread_rng (spec: DESIGN.md).
+ * Packed root format used everywhere below:
+ *   parents   [count][n]  u8   parents[v] < v, parents[0]=parents[1]=parents[n-1]=0
+ *   permitted [count][KW] u64  bit a set <=> action id a is permitted */
+int azd_c21_generate_roots(uint64_t seed, uint64_t epoch, uint64_t first_agent, int count, int n,
+                           int kmin, int kmax, uint8_t *parents, uint64_t *permitted);
+
+/* ------------------------------------------------------------------------- */
+/* Evaluator seam (NablaModel)                                               */
+/* ------------------------------------------------------------------------- */
+typedef struct azd_evaluator azd_evaluator;
+
+typedef struct azd_adam_config { /* dfdx AdamConfig as set at 04-c21-tree.rs:87-92 */
+    float lr;
+    float beta1;
+    float beta2;
+    float eps;
+    float l2; /* WeightDecay::L2 */
+} azd_adam_config;
+
+#define AZD_ACT_NONE 0
+#define AZD_ACT_RELU 1
+#define AZD_ACT_SIGMOID 2
+
+/* ActionModel::new (model/dfdx.rs:36-53): an MLP state_dim -> hidden[0] -> ... -> action_dim,
+ * ReLU between layers, `final_act` on the head (04-c21-tree.rs:46-52), fp32, Adam. */
+int azd_evaluator_create_mlp(azd_evaluator **out, int device, int max_batch, int state_dim,
+                             int action_dim, const int *hidden, int n_hidden, int final_act,
+                             const azd_adam_config *adam, uint64_t seed);
+/* TrivialModel (model/mod.rs:10-23): leaves predictions untouched, loss 0. */
+int azd_evaluator_create_trivial(azd_evaluator **out, int device, int state_dim, int action_dim);
+/* Fixed prediction stream h(agent, call, a): the parity harness'
+ * stand-in for a model, so MLP rounding cannot perturb tree topology. */
+int azd_evaluator_create_hash_stream(azd_evaluator **out, int device, int state_dim, int action_dim,
+                                     uint64_t seed, uint64_t first_agent);
+int azd_evaluator_destroy(azd_evaluator *ev);
+
+/* NablaModel::write_predictions (model/mod.rs:5; dfdx.rs:69-84).
+ * states: batch*state_dim, predictions: batch*action_dim, host memory. */
+int azd_evaluator_write_predictions(azd_evaluator *ev, int batch, const float *states,
+                                    float *predictions);
+/* NablaModel::update_model (model/mod.rs:6-7; dfdx.rs:86-131): w /= sum(w);
+ * L = sum w (pred - obs)^2; backward; Adam.  Returns L in *loss. */
+int azd_evaluator_update_model(azd_evaluator *ev, int batch, const float *states,
+                               const float *observations, const float *action_weights, float *loss);
+/* Same two calls on DEVICE pointers (what the engine uses internally and what a
+ * multi-GPU host calls after its all-gather).  `stream` is a hipStream_t or NULL. */
+int azd_evaluator_write_predictions_dev(azd_evaluator *ev, int batch, const float *d_states,
+                                        float *d_predictions, void *stream);
+int azd_evaluator_update_model_dev(azd_evaluator *ev, int batch, const float *d_states,
+                                   const float *d_observations, const float *d_action_weights,
+                                   float *loss, void *stream);
+/* flat parameter vector: per layer W[out][in] then b[out] (dfdx Linear layout) */
+int64_t azd_evaluator_num_params(azd_evaluator *ev);
+int azd_evaluator_get_params(azd_evaluator *ev, float *out);
+int azd_evaluator_set_params(azd_evaluator *ev, const float *in);
+/* number of evaluator invocations so far (the `call` index of the hash stream) */
+uint64_t azd_evaluator_calls(azd_evaluator *ev);
+
+/* ------------------------------------------------------------------------- */
+/* Engine seam (NablaOptimizer<Space, M, ActionSet>)                         */
+/* ------------------------------------------------------------------------- */
+typedef struct azd_engine azd_engine;
+
+typedef struct azd_engine_config {
+    int space_id;      /* AZD_SPACE_C21 */
+    int n;             /* vertices N of the c21 space (4..AZD_C21_MAX_N) */
+    int batch;         /* BATCH: agents (trees) owned by this engine / GPU */
+    int device;        /* HIP device ordinal */
+    /* per-tree arena capacities; 0 = default sized for 800 calls per epoch */
+    int node_capacity;
+    int arc_capacity;
+    int prediction_capacity;
+    uint64_t first_agent; /* global id of agent 0 (multi-GPU sharding) */
+} azd_engine_config;
+
+/* ArgminData<State, Cost> (az-discrete-opt/src/log.rs:1-11) for the c21 space */
+typedef struct azd_argmin {
+    uint8_t parents[32];
+    uint64_t permitted[4];
+    double lambda_1;           /* Conjecture2Dot1Cost.lambda_1 */
+    int32_t matching_size;     /* Conjecture2Dot1Cost.matching.len() */
+    int32_t matching[32];      /* (parent, child) pairs of the matching */
+    float eval;
+    int32_t agent;             /* tree the state was found in */
+    uint32_t node;             /* its node index in that tree */
+} azd_argmin;
+
+enum { /* indices into azd_engine_counters' output */
+    AZD_CTR_EXPANSIONS = 0,     /* calls that ended on a new non-terminal node (metric numerator) */
+    AZD_CTR_TERMINALS = 1,
+    AZD_CTR_TRANSPOSITIONS = 2,
+    AZD_CTR_VISITED_STEPS = 3,
+    AZD_CTR_SELECT_CALLS = 4,
+    AZD_CTR_SUM_DEG = 5,
+    AZD_CTR_SUM_ACTIONS = 6,
+    AZD_CTR_CASCADE_NODES = 7,
+    AZD_CTR_NEW_PREDS = 8,
+    AZD_CTR_ROOT_EXHAUSTED = 9,
+    AZD_CTR_MAX_FRONTIER = 10,
+    AZD_CTR_MAX_DEPTH = 11,
+    AZD_CTR_CURIOSITY_PAIRS = 12,
+    AZD_CTR_FAILED_AGENTS = 15,
+    AZD_CTR_COUNT = 16
+};
+
+/* Allocates the device arenas.  `ev` may be NULL (external evaluator: drive the
+ * engine with the *_begin/_end pairs and supply predictions yourself). */
+int azd_engine_create(azd_engine **out, const azd_engine_config *cfg, azd_evaluator *ev);
+int azd_engine_destroy(azd_engine *e);
+
+/* NablaOptimizer::par_new (optimizer/mod.rs:39-118).  `init_states` stays on the
+ * host: the caller passes the packed roots it produced. */
+int azd_engine_par_new(azd_engine *e, const uint8_t *parents, const uint64_t *permitted);
+/* NablaOptimizer::par_roll_out_episodes (optimizer/mod.rs:121-191), `n_calls`
+ * times back to back without a host round trip.  n_as_tol crosses the ABI as
+ * table + default (04-c21-tree.rs:136-138).  *improved = number of calls that
+ * returned ArgminImprovement::Improved. */
+int azd_engine_par_roll_out_episodes(azd_engine *e, const uint32_t *n_as_tol, int n_tol,
+                                     uint32_t n_as_tol_default, int n_calls, int *improved);
+/* NablaOptimizer::par_update_model (optimizer/mod.rs:249-281) */
+int azd_engine_par_update_model(azd_engine *e, uint32_t n_obs_tol, float *loss);
+/* NablaOptimizer::par_reset_trees (optimizer/mod.rs:284-360) with the
+ * `modify_root` closure applied by the caller (see azd_c21_modify_roots). */
+int azd_engine_par_reset_trees(azd_engine *e, const uint8_t *parents, const uint64_t *permitted);
+/* NablaOptimizer::argmin_data (optimizer/mod.rs:361) */
+int azd_engine_argmin_data(azd_engine *e, azd_argmin *out);
+
+/* The `modify_root` policy of the c21 driver (04-c21-tree.rs:172-206), seeded;
+ * reads each tree's node_data() (tree/mod.rs:302-307) and writes new packed roots. */
+int azd_c21_modify_roots(azd_engine *e, uint64_t seed, uint64_t epoch, int kmin, int kmax,
+                         uint8_t *parents_out, uint64_t *permitted_out);
+
+/* Split-phase forms of the three calls above, cut at the model call
+ * (optimizer/mod.rs:72, :175-176, :348), for an external NablaModel:
+ * *_begin leaves the state vectors ready, *_end consumes h_theta (host, batch*action_dim). */
+int azd_engine_par_new_begin(azd_engine *e, const uint8_t *parents, const uint64_t *permitted);
+int azd_engine_par_new_end(azd_engine *e, const float *h_theta);
+int azd_engine_roll_out_begin(azd_engine *e, const uint32_t *n_as_tol, int n_tol,
+                              uint32_t n_as_tol_default);
+int azd_engine_roll_out_end(azd_engine *e, const float *h_theta, int *improved);
+int azd_engine_reset_begin(azd_engine *e, const uint8_t *parents, const uint64_t *permitted);
+int azd_engine_reset_end(azd_engine *e, const float *h_theta);
+/* par_update_model without the model call: fills the training triple
+ * (optimizer/mod.rs:262-278).  Host copies (any may be NULL) ... */
+int azd_engine_observe(azd_engine *e, uint32_t n_obs_tol, float *state_vecs, float *observations,
+                       float *action_weights);
+/* ... or the device buffers themselves, for an all-gather across GPUs. */
+int azd_engine_observe_dev(azd_engine *e, uint32_t n_obs_tol, const float **d_state_vecs,
+                           const float **d_observations, const float **d_action_weights);
+int azd_engine_read_state_vecs(azd_engine *e, float *state_vecs); /* batch*state_dim */
+int azd_engine_read_predictions(azd_engine *e, float *h_theta);   /* last h_theta, batch*action_dim */
+
+/* Introspection (SearchTree::{nodes, positions, node_data}, tree/mod.rs:302-315;
+ * get_trees, optimizer/mod.rs:34-36): raw arrays instead of graphviz. */
+int azd_engine_tree_sizes(azd_engine *e, int agent, int *n_nodes, int *n_arcs, int *n_predictions);
+int azd_engine_export_tree(azd_engine *e, int agent, float *c, float *c_star, uint32_t *n_t,
+                           uint32_t *exhausted, uint32_t *act_begin, uint32_t *act_end,
+                           uint64_t *keys, uint32_t *arc_src, uint32_t *arc_dst, uint32_t *arc_pp,
+                           uint32_t *pred_a_id, float *pred_g, int32_t *pred_arc);
+int azd_engine_agent_state(azd_engine *e, int agent, uint8_t *parents, uint64_t *permitted,
+                           uint64_t *path, uint32_t *state_pos, double *lambda_1,
+                           int *matching_size);
+int azd_engine_counters(azd_engine *e, uint64_t *out /* [AZD_CTR_COUNT] */);
+/* ms of GPU time spent in the tree kernels / evaluator since creation (HIP events
+ * on the engine's stream; enabled by azd_engine_set_timing) */
+int azd_engine_set_timing(azd_engine *e, int enabled);
+int azd_engine_timing(azd_engine *e, double *tree_ms, double *evaluator_ms, uint64_t *tree_launches);
+void *azd_engine_stream(azd_engine *e); /* hipStream_t the engine launches on */
+
+/* Parity probe for the two f32 primitives the selection rule (tree/next_action.rs:70,81) depends
+ * on bit-for-bit: out[2i] = sqrt(|in[2i] - in[2i+1]|), out[2i+1] = in[2i] - (in[2i] - in[2i+1]).
+ * Host buffers of 2*n floats. */
+int azd_debug_probe_math(int device, const float *in, float *out, int n);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* AZDOPT_AMD_H */
