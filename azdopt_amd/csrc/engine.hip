@@ -767,11 +767,11 @@ int azd_debug_probe_math(int device, const float *in, float *out, int n) {
     AZD_HIP(hipSetDevice(device));
     float *d_in = nullptr, *d_out = nullptr;
     AZD_HIP(hipMalloc(&d_in, (size_t)n * 8));
-    AZD_HIP(hipMalloc(&d_out, (size_t)n * 8));
+    AZD_HIP(hipMalloc(&d_out, (size_t)n * 16));
     AZD_HIP(hipMemcpy(d_in, in, (size_t)n * 8, hipMemcpyHostToDevice));
     azd::launch_probe_math(d_in, d_out, n, nullptr);
     hipError_t he = hipDeviceSynchronize();
-    if (he == hipSuccess) he = hipMemcpy(out, d_out, (size_t)n * 8, hipMemcpyDeviceToHost);
+    if (he == hipSuccess) he = hipMemcpy(out, d_out, (size_t)n * 16, hipMemcpyDeviceToHost);
     (void)hipFree(d_in);
     (void)hipFree(d_out);
     if (he != hipSuccess) return azd::hip_fail(he, "probe_math");

@@ -38,6 +38,10 @@ __device__ __forceinline__ uint32_t ordf(float f) {
     uint32_t u = __float_as_uint(f);
     return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
 }
+// Correctly rounded f32 square root (the oracle's sqrtss / np.sqrt): an f64 square root of an f32
+// value rounded back to f32 is exact-rounded (53 >= 2*24 + 2 bits), independent of the f32 sqrt
+// expansion hipcc picks.
+__device__ __forceinline__ float azd_sqrt(float x) { return (float)sqrt((double)x); }
 __device__ __forceinline__ uint64_t wave_min_u64(uint64_t v) {
 #pragma unroll
     for (int off = 32; off >= 1; off >>= 1) {
@@ -627,7 +631,7 @@ __global__ __launch_bounds__(64) void k_rollout(Arenas a, TolTable tol) {
                             key = ((uint64_t)(~ordf(v)) << 32) | (uint64_t)(0xFFFFFFFFu - idx);
                         } else {
                             float sum = 0.0f; // f32 sum, sequential, newest child first
-                            for (uint32_t j = 0; j < n_exp; ++j) sum = sum + __fsqrt_rn(fabsf(lds_kids()[j] - v));
+                            for (uint32_t j = 0; j < n_exp; ++j) sum = sum + azd_sqrt(fabsf(lds_kids()[j] - v));
                             // max_by: last maximum  ->  maximise (ord(sum), idx)
                             key = ((uint64_t)ordf(sum) << 32) | (uint64_t)idx;
                         }
@@ -921,15 +925,18 @@ __global__ void k_hash_predictions(float *out, int batch, int action_dim, uint64
     out[i] = (float)(r >> 40) * (1.0f / 16777216.0f);
 }
 
-// parity probe for the two f32 primitives the selection rule depends on:
-// out[2i] = sqrt(|in[2i] - in[2i+1]|) (correctly rounded), out[2i+1] = in[2i] - (in[2i] - in[2i+1])
+// parity probe for the f32 primitives the selection rule depends on; four outputs per input pair:
+//   [0] the kernel's own sqrt(|x - y|) (azd_sqrt)   [1] sqrtf   [2] __fsqrt_rn   [3] x - (x - y)
 __global__ void k_probe_math(const float *in, float *out, int n) {
     int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     float x = in[2 * i], y = in[2 * i + 1];
-    out[2 * i] = __fsqrt_rn(fabsf(x - y));
+    float d = fabsf(x - y);
+    out[4 * i] = azd_sqrt(d);
+    out[4 * i + 1] = sqrtf(d);
+    out[4 * i + 2] = __fsqrt_rn(d);
     float g = x - y;
-    out[2 * i + 1] = x - g;
+    out[4 * i + 3] = x - g;
 }
 
 // ---------------------------------------------------------------- launchers

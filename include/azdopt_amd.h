@@ -230,8 +230,8 @@ int azd_engine_timing(azd_engine *e, double *tree_ms, double *evaluator_ms, uint
 void *azd_engine_stream(azd_engine *e); /* hipStream_t the engine launches on */
 
 /* Parity probe for the two f32 primitives the selection rule (tree/next_action.rs:70,81) depends
- * on bit-for-bit: out[2i] = sqrt(|in[2i] - in[2i+1]|), out[2i+1] = in[2i] - (in[2i] - in[2i+1]).
- * Host buffers of 2*n floats. */
+ * on bit-for-bit.  in: 2*n floats (pairs x, y); out: 4*n floats per pair:
+ * [0] the kernels' sqrt(|x - y|), [1] sqrtf, [2] __fsqrt_rn (diagnostics), [3] x - (x - y). */
 int azd_debug_probe_math(int device, const float *in, float *out, int n);
 
 #ifdef __cplusplus

@@ -43,15 +43,15 @@ def test_f32_primitives_bit_exact(az):
     x[: n // 2] *= np.float32(1e-38)  # subnormal differences
     x[n // 2: n] = np.nextafter(x[n // 2: n], np.float32(2))  # 1-ulp neighbours
     x[2 * 100] = x[2 * 100 + 1]  # exact zero
-    out = np.zeros(2 * n, np.float32)
+    out = np.zeros(4 * n, np.float32)
     L = az.lib()
     from azdopt_amd import _lib
     _lib.check(L.azd_debug_probe_math(0, _lib.ptr(x), _lib.ptr(out), n), "probe")
     a, b = x[0::2], x[1::2]
     want_sqrt = np.sqrt(np.abs(a - b))
     want_sub = a - (a - b)
-    assert np.array_equal(out[0::2].view(np.uint32), want_sqrt.view(np.uint32))
-    assert np.array_equal(out[1::2].view(np.uint32), want_sub.view(np.uint32))
+    assert np.array_equal(out[0::4].view(np.uint32), want_sqrt.view(np.uint32))
+    assert np.array_equal(out[3::4].view(np.uint32), want_sub.view(np.uint32))
 
 
 def test_hash_stream_matches_oracle(az, orc):
