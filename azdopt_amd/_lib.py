@@ -7,13 +7,14 @@ import os
 import subprocess
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libazdopt_amd.so")
+LIB_PATH = os.environ.get("AZD_LIB", os.path.join(_HERE, "libazdopt_amd.so"))
 _LIB = None
 
 CTR = dict(EXPANSIONS=0, TERMINALS=1, TRANSPOSITIONS=2, VISITED_STEPS=3, SELECT_CALLS=4, SUM_DEG=5,
            SUM_ACTIONS=6, CASCADE_NODES=7, NEW_PREDS=8, ROOT_EXHAUSTED=9, MAX_FRONTIER=10, MAX_DEPTH=11,
-           CURIOSITY_PAIRS=12, FAILED=15)
-CTR_COUNT = 16
+           CURIOSITY_PAIRS=12, FAILED=15, TICKS_TOTAL=16, TICKS_SELECT=17, TICKS_LOOKUP=18, TICKS_NEWNODE=19,
+           TICKS_CASCADE=20, TICKS_MAX_CALL=21, TICKS_LAMBDA=22, TICKS_MATCHING=23)
+CTR_COUNT = 24
 
 ACT_NONE, ACT_RELU, ACT_SIGMOID = 0, 1, 2
 SPACE_C21 = 1
@@ -115,6 +116,7 @@ def lib():
     sig("azd_engine_timing", C.c_int, vp, C.POINTER(C.c_double), C.POINTER(C.c_double), u64p)
     sig("azd_engine_stream", vp, vp)
     sig("azd_debug_probe_math", C.c_int, C.c_int, vp, vp, C.c_int)
+    sig("azd_debug_probe_cost", C.c_int, C.c_int, vp, C.c_int, C.c_int, C.c_int, C.c_int, vp, vp, f32p)
     _LIB = L
     return L
 

@@ -191,7 +191,13 @@ int upload_roots(azd_engine *e, const uint8_t *parents, const uint64_t *permitte
     // validate on the host what the kernels assume (parents[v] < v; at most MAX_NODE_ACTIONS permitted)
     for (int i = 0; i < a.B; ++i) {
         const uint8_t *p = parents + (size_t)i * a.n;
-        if (p[0] != 0) return AZD_ERR_INVALID_ARGUMENT;
+        // rooted_tree/mod.rs:14-20: parents[0] = parents[1] = parents[N-1] = 0, and no action ever
+        // re-parents vertex N-1 (action children are 2..N-2), so N-1 and N-2 stay leaves -- the
+        // lambda_1 kernel gives them no accumulator slot
+        if (p[0] != 0 || p[a.n - 1] != 0) {
+            g_last_error = "root parents[0] and parents[N-1] must be 0";
+            return AZD_ERR_INVALID_ARGUMENT;
+        }
         for (int v = 1; v < a.n; ++v)
             if (p[v] >= v) {
                 g_last_error = "root parents[v] must be < v";
@@ -734,7 +740,7 @@ int azd_engine_counters(azd_engine *e, uint64_t *out) {
     for (int i = 0; i < a.B; ++i) {
         for (int k = 0; k < azd::NUM_COUNTERS; ++k) {
             unsigned long long v = h[(size_t)i * azd::NUM_COUNTERS + k];
-            if (k == AZD_CTR_MAX_FRONTIER || k == AZD_CTR_MAX_DEPTH) out[k] = std::max<uint64_t>(out[k], v);
+            if (k == AZD_CTR_MAX_FRONTIER || k == AZD_CTR_MAX_DEPTH || k == AZD_CTR_TICKS_MAX_CALL) out[k] = std::max<uint64_t>(out[k], v);
             else out[k] += v;
         }
     }
@@ -775,6 +781,48 @@ int azd_debug_probe_math(int device, const float *in, float *out, int n) {
     (void)hipFree(d_in);
     (void)hipFree(d_out);
     if (he != hipSuccess) return azd::hip_fail(he, "probe_math");
+    return AZD_OK;
+}
+
+int azd_debug_probe_cost(int device, const uint8_t *parents, int n, int count, int reps, int full, double *lambda_1,
+                         int *matching_size, float *ms) {
+    if (!parents || !lambda_1 || !matching_size || n < 4 || n > AZD_C21_MAX_N || count <= 0 || reps <= 0)
+        return AZD_ERR_INVALID_ARGUMENT;
+    int st = azd::device_ok(device);
+    if (st) return st;
+    AZD_HIP(hipSetDevice(device));
+    for (int i = 0; i < count; ++i) {
+        const uint8_t *p = parents + (size_t)i * n;
+        if (p[0] != 0 || p[n - 1] != 0) return AZD_ERR_INVALID_ARGUMENT;
+        for (int v = 1; v < n; ++v)
+            if (p[v] >= v) return AZD_ERR_INVALID_ARGUMENT;
+    }
+    uint8_t *d_p = nullptr;
+    double *d_l = nullptr;
+    int *d_m = nullptr;
+    hipEvent_t e0, e1;
+    AZD_HIP(hipMalloc(&d_p, (size_t)count * n));
+    AZD_HIP(hipMalloc(&d_l, (size_t)count * 8));
+    AZD_HIP(hipMalloc(&d_m, (size_t)count * 4));
+    AZD_HIP(hipEventCreate(&e0));
+    AZD_HIP(hipEventCreate(&e1));
+    AZD_HIP(hipMemcpy(d_p, parents, (size_t)count * n, hipMemcpyHostToDevice));
+    azd::launch_probe_cost(d_p, n, count, 1, full, d_l, d_m, nullptr); // warm-up
+    AZD_HIP(hipEventRecord(e0, nullptr));
+    azd::launch_probe_cost(d_p, n, count, reps, full, d_l, d_m, nullptr);
+    AZD_HIP(hipEventRecord(e1, nullptr));
+    hipError_t he = hipDeviceSynchronize();
+    float t = 0.f;
+    if (he == hipSuccess) he = hipEventElapsedTime(&t, e0, e1);
+    if (he == hipSuccess) he = hipMemcpy(lambda_1, d_l, (size_t)count * 8, hipMemcpyDeviceToHost);
+    if (he == hipSuccess) he = hipMemcpy(matching_size, d_m, (size_t)count * 4, hipMemcpyDeviceToHost);
+    (void)hipFree(d_p);
+    (void)hipFree(d_l);
+    (void)hipFree(d_m);
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+    if (he != hipSuccess) return azd::hip_fail(he, "probe_cost");
+    if (ms) *ms = t;
     return AZD_OK;
 }
 

@@ -23,7 +23,7 @@ constexpr int PRED_CHUNKS = 2;               // a node holds at most 64*PRED_CHU
 constexpr int MAX_NODE_ACTIONS = 64 * PRED_CHUNKS;
 constexpr int FRONTIER_CAP = 256;            // LDS-staged cascade frontier per tree
 constexpr int MAX_TOL = 32;
-constexpr int NUM_COUNTERS = 16;
+constexpr int NUM_COUNTERS = 24; // 0..15 public counters, 16..23 phase ticks (AZD_PHASE_PROFILE builds)
 
 struct __attribute__((aligned(16))) NodeRec {
     float c;            // evaluate(cost(state))
@@ -127,6 +127,8 @@ void launch_argmin(const Arenas &a, int init_mode, void *stream);
 void launch_observe(const Arenas &a, uint32_t n_obs_tol, void *stream);
 void launch_hash_predictions(float *d_out, int batch, int action_dim, uint64_t seed, uint64_t first_agent,
                              uint64_t call, void *stream);
+void launch_probe_cost(const uint8_t *d_parents, int n, int count, int reps, int full, double *d_lam, int *d_mu,
+                       void *stream);
 void launch_probe_math(const float *d_in, float *d_out, int n, void *stream); // sqrtf / sub parity probe (tests)
 
 } // namespace azd

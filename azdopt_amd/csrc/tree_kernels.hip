@@ -31,6 +31,24 @@ namespace azd {
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");   \
     } while (0)
 
+// Diagnostic build (make PROFILE=1): 100 MHz wall-clock stamps per phase, accumulated into counter
+// slots 16..22.  In the product build PH_NOW() folds to 0 and the adds vanish.
+#ifdef AZD_PHASE_PROFILE
+#define PH_NOW() ((unsigned long long)wall_clock64())
+#else
+#define PH_NOW() (0ull)
+#endif
+
+// per-call counters live in the wave's LDS block `s` (lane 0 updates; values are wave-uniform)
+#define CTR_ADD(K, V)                                            \
+    do {                                                         \
+        if (LANE == 0) s.ctr[K] += (unsigned long long)(V);      \
+    } while (0)
+#define CTR_MAX(K, V)                                                                        \
+    do {                                                                                     \
+        if (LANE == 0 && (unsigned long long)(V) > s.ctr[K]) s.ctr[K] = (unsigned long long)(V); \
+    } while (0)
+
 // ---------------------------------------------------------------- small helpers
 __device__ __forceinline__ uint32_t ordf(float f) {
     // order-preserving map f32 -> u32 (after folding -0.0 into +0.0, as partial_cmp treats them equal)
@@ -113,26 +131,27 @@ __device__ __forceinline__ uint32_t key_hash(const uint64_t (&k)[KW]) {
 
 // ---------------------------------------------------------------- per-wave LDS
 // One block = one wave.  The selection scratch (kids / tmp_arc), the cascade frontier and the
-// lambda_1 accumulators are never live together, so they share the dynamic LDS region
-// (dyn_lds_bytes(n) per block: 8.5 KiB at N = 19, which keeps 16 agents resident per CU).
+// lambda_1 columns are never live together, so they share the dynamic LDS region (8 KiB per agent
+// at N = 19).
 struct WaveLds {
     uint8_t par[PARENTS_STRIDE];     // parents of the agent's current state
     uint8_t act_parent[256];         // action id -> (parent, child), ordered_edge.rs:40-42
     uint8_t act_child[256];
+    unsigned long long ctr[NUM_COUNTERS]; // per-call counters (wave-uniform; kept out of the register file)
 };
 // views of the dynamic region
 extern __shared__ double azd_dyn_lds[];
-__device__ __forceinline__ double *lds_acc() { return azd_dyn_lds; }     // [n-2][64]: acc[v-1][lane], v = 1..n-2
 __device__ __forceinline__ float *lds_kids() { return (float *)azd_dyn_lds; } // [MAX_NODE_ACTIONS] c_star, newest arc first
 __device__ __forceinline__ uint32_t *lds_tmp_arc() { return (uint32_t *)azd_dyn_lds + MAX_NODE_ACTIONS; }
 __device__ __forceinline__ uint32_t *lds_fr_id() { return (uint32_t *)azd_dyn_lds; }                 // [2][FRONTIER_CAP]
 __device__ __forceinline__ uint32_t *lds_fr_x() { return (uint32_t *)azd_dyn_lds + 2 * FRONTIER_CAP; } // [2][FRONTIER_CAP]
+__device__ __forceinline__ double *lds_pq() { return azd_dyn_lds; } // [2][n-2][32] lambda_1 (P, Q) columns
 static size_t dyn_lds_bytes(int n) {
-    size_t acc = (size_t)(n - 2) * 64 * sizeof(double);
     size_t fr = (size_t)4 * FRONTIER_CAP * sizeof(uint32_t);
     size_t sel = (size_t)2 * MAX_NODE_ACTIONS * sizeof(uint32_t);
-    size_t m = acc > fr ? acc : fr;
-    return m > sel ? m : sel;
+    size_t pq = (size_t)2 * (n > 2 ? n - 2 : 1) * 32 * sizeof(double);
+    size_t m = fr > sel ? fr : sel;
+    return m > pq ? m : pq;
 }
 
 // action id -> (parent, child): index(parent, child) = child(child-1)/2 + parent - 1
@@ -167,36 +186,114 @@ __device__ __forceinline__ void do_act(WaveLds &s, uint64_t (&perm)[KW], uint32_
     WAVE_SYNC();
 }
 
-// lambda_1 cost contract: pivots of the leaf-first LDL^T of xI - A at 64 trial
-// points per round, ten rounds of multisection on [1, N].  ordered_edge.rs:72-82 (faer) stand-in.
-__device__ double lambda1_wave(WaveLds &s, int n) {
+__device__ __forceinline__ uint64_t wave_or_u64(uint64_t v) {
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) v |= __shfl_xor(v, off, 64);
+    return v;
+}
+
+// lambda_1 cost contract (DESIGN.md "lambda_1"; stands in for faer at ordered_edge.rs:72-82):
+// phi_v = characteristic polynomial of the subtree below v is positive for every v  <=>  x > lambda_1.
+// Division-free fold of each vertex into its parent's running pair (P, Q), initially (1, 0):
+//     phi = x P[v] - Q[v];   Q[p] = Q[p] phi + P[p] P[v];   P[p] = P[p] phi        (v = N-1 .. 1)
+// at 32 trial points per round (33-section of the bracket; lanes l and l+32 duplicate each other),
+// at most 12 rounds.  FULL = false (node costs): stop once both bracket ends round to the same f32,
+// which is all `lambda_1 as f32` (04-c21-tree.rs:100) can see.
+// Shape of the loop: the kernel waits for its slowest agent, so single-wave latency is what counts,
+// and on this machine that means NO BRANCHES in the vertex loop (a taken scalar branch costs more
+// than the six f64 operations of a fold).  Every vertex runs the same straight-line body; the
+// wave-uniform tree only enters through LDS addresses: per-lane (P, Q) live in LDS columns
+// [slot][lane], slot(v) = v for v = 0..n-3 (vertices n-1 and n-2 are leaves by construction and are
+// peeled), and parents are packed 5 bits each into two scalars, so the loop issues no LDS read for
+// the tree itself.  Four ds_read_b64 go out together per vertex, then six DP ops, then two writes.
+// parents[] as two wave-uniform scalars, 5 bits per vertex (12 vertices per word)
+struct PackedTree {
+    uint64_t par0, par1;
+};
+__device__ __forceinline__ PackedTree pack_tree(const WaveLds &s, int n) {
+    uint64_t w0 = 0, w1 = 0;
+    if (LANE >= 1 && LANE < n) {
+        uint64_t pv = s.par[LANE];
+        if (LANE < 12) w0 = pv << (5 * LANE);
+        else w1 = pv << (5 * (LANE - 12));
+    }
+    PackedTree t;
+    t.par0 = uni64(wave_or_u64(w0));
+    t.par1 = uni64(wave_or_u64(w1));
+    return t;
+}
+
+// |maximum matching| of the tree.  The reference strips leaves round by round
+// (ordered_edge.rs:94-124; restated literally in matching_wave below, which k_argmin uses to report
+// the edges); that procedure only ever matches a leaf of the remaining forest with its parent,
+// which is always safe, so its size is the matching number -- here computed by the one-pass
+// children-before-parents greedy on the scalar unit (tests compare both against the oracle).
+__device__ __forceinline__ int matching_size_wave(const PackedTree &t, int n) {
+    uint32_t matched = 0;
+    int m = 0;
+    for (int v = n - 1; v >= 1; --v) {
+        const uint32_t p = (uint32_t)((v < 12 ? (t.par0 >> (5 * v)) : (t.par1 >> (5 * (v - 12)))) & 31ull);
+        const uint32_t free_both = ~(matched >> v) & ~(matched >> p) & 1u;
+        matched |= (free_both << v) | (free_both << p);
+        m += (int)free_both;
+    }
+    return m;
+}
+
+template <bool FULL>
+__device__ double lambda1_wave(const PackedTree &t, int n) {
+    const uint64_t par0 = t.par0, par1 = t.par1;
+    const int nslot = n > 2 ? n - 2 : 1;
+    const int l = LANE & 31;
+    double *Pm = lds_pq() + l;
+    double *Qm = Pm + nslot * 32;
+    const int p_last = (int)(((n - 1) < 12 ? (par0 >> (5 * (n - 1))) : (par1 >> (5 * (n - 13)))) & 31ull);
+    const int p_prev = (int)(((n - 2) < 12 ? (par0 >> (5 * (n - 2))) : (par1 >> (5 * (n - 14)))) & 31ull);
     double lo = 1.0, hi = (double)n;
-    double *acc = lds_acc();
-    for (int round = 0; round < 10; ++round) {
-        double w = (hi - lo) / 65.0;
-        double step = w * (double)(LANE + 1);
-        double x = lo + step;
-        for (int v = 1; v < n - 1; ++v) acc[(v - 1) * 64 + LANE] = 0.0;
-        double acc0 = 0.0;
-        bool ok = true;
-        for (int v = n - 1; v >= 1; --v) {
-            // vertex n-1 is always a leaf (no vertex has a larger index): its accumulator is 0
-            double av = (v == n - 1) ? 0.0 : acc[(v - 1) * 64 + LANE];
-            double d = x - av;
-            if (!(d > 0.0)) ok = false;
-            double inv = 1.0 / d;
-            int p = s.par[v];
-            if (p == 0) acc0 = acc0 + inv;
-            else acc[(p - 1) * 64 + LANE] = acc[(p - 1) * 64 + LANE] + inv;
+    for (int round = 0; round < 12; ++round) {
+        if (!FULL && (float)lo == (float)hi) break;
+        const double w = (hi - lo) / 33.0;
+        const double step = w * (double)(l + 1);
+        const double x = lo + step;
+        for (int v = 0; v < nslot; ++v) {
+            Pm[v * 32] = 1.0;
+            Qm[v * 32] = 0.0;
         }
-        double d0 = x - acc0;
-        if (!(d0 > 0.0)) ok = false;
-        uint64_t m = __ballot(ok);
-        int first = m ? first_lane(m) : 64;
-        double x_prev = __shfl(x, first > 0 ? first - 1 : 0, 64);
-        double x_first = __shfl(x, first < 64 ? first : 63, 64);
-        double nlo = first > 0 ? x_prev : lo;
-        double nhi = first < 64 ? x_first : hi;
+        bool ok = x > 0.0;
+        // peeled leaves n-1 and n-2 (n >= 4): phi = x*1 - 0 = x, psi = 1
+        {
+            const double pp = Pm[p_last * 32], qp = Qm[p_last * 32];
+            const double qphi = qp * x, ppsi = pp * 1.0;
+            Qm[p_last * 32] = qphi + ppsi;
+            Pm[p_last * 32] = pp * x;
+        }
+        {
+            const double pp = Pm[p_prev * 32], qp = Qm[p_prev * 32];
+            const double qphi = qp * x, ppsi = pp * 1.0;
+            Qm[p_prev * 32] = qphi + ppsi;
+            Pm[p_prev * 32] = pp * x;
+        }
+        for (int v = n - 3; v >= 1; --v) {
+            const int p = (int)((v < 12 ? (par0 >> (5 * v)) : (par1 >> (5 * (v - 12)))) & 31ull);
+            const double pv = Pm[v * 32], qv = Qm[v * 32];
+            const double pp = Pm[p * 32], qp = Qm[p * 32];
+            const double xp = x * pv;
+            const double phi = xp - qv;
+            ok = ok && (phi > 0.0);
+            const double qphi = qp * phi;
+            const double ppsi = pp * pv;
+            Qm[p * 32] = qphi + ppsi;
+            Pm[p * 32] = pp * phi;
+        }
+        const double xp0 = x * Pm[0];
+        const double phi0 = xp0 - Qm[0];
+        ok = ok && (phi0 > 0.0);
+        const uint32_t m = (uint32_t)__ballot(ok);
+        const int first = m ? (__ffs((int)m) - 1) : 32;
+        const double x_prev = __shfl(x, first > 0 ? first - 1 : 0, 64);
+        const double x_first = __shfl(x, first < 32 ? first : 31, 64);
+        const double nlo = first > 0 ? x_prev : lo;
+        const double nhi = first < 32 ? x_first : hi;
         lo = nlo;
         hi = nhi;
     }
@@ -293,7 +390,6 @@ struct Agent {
     uint32_t flags;
     float cand_c;
     uint32_t cand_node;
-    unsigned long long ctr[NUM_COUNTERS];
 };
 
 __device__ __forceinline__ bool node_active(const NodeRec &r) { return r.act_begin + r.exhausted < r.act_end; }
@@ -319,7 +415,7 @@ __device__ void cascade(const Arenas &a, Agent<KW> &ag, WaveLds &s, uint32_t src
     while (n_cur != 0) {
         uint32_t n_nxt = 0;
         const int nxt = cur ^ 1;
-        if (n_cur > ag.ctr[10]) ag.ctr[10] = n_cur;
+        CTR_MAX(10, n_cur);
         for (uint32_t i = 0; i < n_cur; ++i) {
             uint32_t u = lds_fr_id()[cur * FRONTIER_CAP + i];
             uint32_t x = lds_fr_x()[cur * FRONTIER_CAP + i];
@@ -333,7 +429,7 @@ __device__ void cascade(const Arenas &a, Agent<KW> &ag, WaveLds &s, uint32_t src
                 ag.nodes[u].n_t = r.n_t;
                 ag.nodes[u].exhausted = r.exhausted;
             }
-            ag.ctr[7] += 1;
+            CTR_ADD(7, 1);
             uint32_t up_x = node_active(r) ? 0u : 1u;
             uint32_t e = r.first_in;
             while (e != NONE) {
@@ -391,7 +487,7 @@ __device__ __forceinline__ uint32_t add_arc(Agent<KW> &ag, uint32_t src, uint32_
 }
 
 // ---------------------------------------------------------------- kernels
-template <int KW>
+template <int KW, bool BIG>
 __global__ __launch_bounds__(64) void k_init_roots(Arenas a, const uint8_t *__restrict__ parents,
                                                    const uint64_t *__restrict__ permitted) {
     __shared__ WaveLds s;
@@ -416,8 +512,9 @@ __global__ __launch_bounds__(64) void k_init_roots(Arenas a, const uint8_t *__re
     }
     WAVE_SYNC();
     // optimizer/mod.rs:63 costs = space.cost(root)
-    double lam = lambda1_wave(s, n);
-    int mu = matching_wave(s, n, nullptr);
+    const PackedTree pt = pack_tree(s, n);
+    double lam = lambda1_wave<false>(pt, n);
+    int mu = matching_size_wave(pt, n);
     float c = c21_eval(a.eval_slope, lam, mu);
     // SearchTree::clear + add_node(P::new(), StateWeight::new(c)) (optimizer/mod.rs:81-84, :353-356)
     uint32_t *ht = a.ht + (size_t)t * a.ht_cap;
@@ -507,7 +604,7 @@ __global__ __launch_bounds__(64) void k_add_actions(Arenas a, int root_mode) {
 }
 
 // tree/mod.rs:113-232 roll_out_episodes for every agent (optimizer/mod.rs:159-174)
-template <int KW>
+template <int KW, bool BIG>
 __global__ __launch_bounds__(64) void k_rollout(Arenas a, TolTable tol) {
     __shared__ WaveLds s;
     const int t = blockIdx.x;
@@ -526,7 +623,7 @@ __global__ __launch_bounds__(64) void k_rollout(Arenas a, TolTable tol) {
     ag.cand_c = a.cand_c[t];
     ag.cand_node = a.cand_node[t];
 #pragma unroll
-    for (int k = 0; k < NUM_COUNTERS; ++k) ag.ctr[k] = 0;
+    for (int k = LANE; k < NUM_COUNTERS; k += 64) s.ctr[k] = 0;
 
     build_action_table(s, A);
     if (LANE < PARENTS_STRIDE) s.par[LANE] = a.cur_parents[(size_t)t * PARENTS_STRIDE + LANE];
@@ -542,12 +639,14 @@ __global__ __launch_bounds__(64) void k_rollout(Arenas a, TolTable tol) {
     WAVE_SYNC();
 
     bool expanded_new = false;
+    const unsigned long long ph_begin = PH_NOW();
     for (uint32_t guard = 0;; ++guard) {
         if (guard > (1u << 22)) {
             ag.flags |= FLAG_LOOP_GUARD;
             break;
         }
         // ---- next_action (next_action.rs:11-26)
+        const unsigned long long ph_sel0 = PH_NOW();
         const NodeRec rec = ag.nodes[pos];
         const int depth = mask_count<KW>(path);
         const uint32_t tl = depth < tol.n_tol ? tol.tol[depth] : tol.tol_default;
@@ -555,8 +654,8 @@ __global__ __launch_bounds__(64) void k_rollout(Arenas a, TolTable tol) {
         uint32_t sel_pp = 0, sel_child = 0, sel_aid = 0;
         if (node_active(rec)) {
             const uint32_t nact = rec.act_end - rec.act_begin;
-            ag.ctr[4] += 1;
-            ag.ctr[6] += nact;
+            CTR_ADD(4, 1);
+            CTR_ADD(6, nact);
             PredRec p[PRED_CHUNKS];
             bool valid[PRED_CHUNKS], expd[PRED_CHUNKS];
             float k_cstar[PRED_CHUNKS];
@@ -580,7 +679,7 @@ __global__ __launch_bounds__(64) void k_rollout(Arenas a, TolTable tol) {
                 exp_mask[ch] = __ballot(expd[ch]);
                 n_exp += (uint32_t)__popcll(exp_mask[ch]);
             }
-            ag.ctr[5] += n_exp;
+            CTR_ADD(5, n_exp);
             // ---- revisit_choice (next_action.rs:28-53): first-min of (n_t, c_t_star) over ACTIVE
             // children in newest-arc-first order  ==  min key, ties -> largest arc id
             uint64_t kmin = rkey[0];
@@ -639,7 +738,7 @@ __global__ __launch_bounds__(64) void k_rollout(Arenas a, TolTable tol) {
                         has_cand = true;
                     }
                 }
-                ag.ctr[12] += (unsigned long long)n_exp * (unsigned long long)(nact - n_exp);
+                CTR_ADD(12, (unsigned long long)n_exp * (unsigned long long)(nact - n_exp));
                 const bool any_cand = __ballot(has_cand) != 0;
                 best = wave_max_u64(has_cand ? best : 0ull);
                 if (any_cand) {
@@ -665,17 +764,18 @@ __global__ __launch_bounds__(64) void k_rollout(Arenas a, TolTable tol) {
         }
         kind = (int)uni((uint32_t)kind);
         sel_aid = uni(sel_aid);
+        CTR_ADD(17, PH_NOW() - ph_sel0);
 
         if (kind == 1) { // Visited (tree/mod.rs:139-151)
             sel_child = uni(sel_child);
             path[sel_aid >> 6] |= 1ull << (sel_aid & 63u);
             do_act<KW>(s, perm, sel_aid);
             pos = sel_child;
-            ag.ctr[3] += 1;
+            CTR_ADD(3, 1);
             continue;
         }
         if (kind == 0) { // None (tree/mod.rs:220-229)
-            if (mask_empty<KW>(path)) ag.ctr[9] += 1;
+            if (mask_empty<KW>(path)) CTR_ADD(9, 1);
             else ag.flags |= FLAG_UNREACHABLE;
             break;
         }
@@ -684,21 +784,25 @@ __global__ __launch_bounds__(64) void k_rollout(Arenas a, TolTable tol) {
         path[sel_aid >> 6] |= 1ull << (sel_aid & 63u);
         {
             uint64_t d = (uint64_t)mask_count<KW>(path);
-            if (d > ag.ctr[11]) ag.ctr[11] = d;
+            CTR_MAX(11, d);
         }
         if (ag.n_arcs >= a.arc_cap) {
             ag.flags |= FLAG_ARC_CAP;
             break;
         }
         uint32_t ins_slot = NONE;
+        const unsigned long long ph_lk0 = PH_NOW();
         uint32_t hit = ht_lookup<KW>(ag.ht, a.ht_cap - 1, ag.keys, path, &ins_slot);
         hit = uni(hit);
+        CTR_ADD(18, PH_NOW() - ph_lk0);
         bool reset_to_root = false;
         if (hit != NONE) { // transposition (tree/mod.rs:172-179)
             add_arc<KW>(ag, pos, hit, sel_pp);
             WAVE_SYNC();
+            const unsigned long long ph_c0 = PH_NOW();
             cascade<KW>(a, ag, s, pos, hit, true);
-            ag.ctr[2] += 1;
+            CTR_ADD(20, PH_NOW() - ph_c0);
+            CTR_ADD(2, 1);
             reset_to_root = true;
         } else { // new node (tree/mod.rs:180-216)
             ins_slot = uni(ins_slot);
@@ -710,10 +814,17 @@ __global__ __launch_bounds__(64) void k_rollout(Arenas a, TolTable tol) {
                 ag.flags |= FLAG_HT_FULL;
                 break;
             }
+            const unsigned long long ph_n0 = PH_NOW();
             do_act<KW>(s, perm, sel_aid);
-            cur_lambda = lambda1_wave(s, n);
-            cur_mu = matching_wave(s, n, nullptr);
+            const unsigned long long ph_l0 = PH_NOW();
+            const PackedTree pt = pack_tree(s, n);
+            cur_lambda = lambda1_wave<false>(pt, n);
+            const unsigned long long ph_l1 = PH_NOW();
+            cur_mu = matching_size_wave(pt, n);
+            CTR_ADD(22, ph_l1 - ph_l0);
+            CTR_ADD(23, PH_NOW() - ph_l1);
             const float c_as = c21_eval(a.eval_slope, cur_lambda, cur_mu);
+            CTR_ADD(19, PH_NOW() - ph_n0);
             const uint32_t v = ag.n_nodes;
             if (LANE == 0) {
                 NodeRec r;
@@ -736,12 +847,14 @@ __global__ __launch_bounds__(64) void k_rollout(Arenas a, TolTable tol) {
 #pragma unroll
             for (int w = 0; w < KW; ++w) legal[w] = perm[w] & ~cur[w];
             if (mask_empty<KW>(legal)) { // terminal: is_terminal, nabla/space/mod.rs:23-25
+                const unsigned long long ph_c0 = PH_NOW();
                 cascade<KW>(a, ag, s, pos, v, false);
-                ag.ctr[1] += 1;
+                CTR_ADD(20, PH_NOW() - ph_c0);
+                CTR_ADD(1, 1);
                 reset_to_root = true;
             } else {
                 pos = v;
-                ag.ctr[0] += 1;
+                CTR_ADD(0, 1);
                 expanded_new = true;
                 break;
             }
@@ -761,6 +874,8 @@ __global__ __launch_bounds__(64) void k_rollout(Arenas a, TolTable tol) {
     }
 
     // ---- write back; optimizer/mod.rs:171-173 write_vec iff the path is non-empty
+    CTR_ADD(16, PH_NOW() - ph_begin);
+    CTR_ADD(21, PH_NOW() - ph_begin);
     WAVE_SYNC();
     if (expanded_new) write_state_vec<KW>(s, perm, A, a.state_vecs + (size_t)t * a.S);
     if (LANE < PARENTS_STRIDE) a.cur_parents[(size_t)t * PARENTS_STRIDE + LANE] = s.par[LANE];
@@ -784,8 +899,8 @@ __global__ __launch_bounds__(64) void k_rollout(Arenas a, TolTable tol) {
         unsigned long long *ctr = a.counters + (size_t)t * NUM_COUNTERS;
 #pragma unroll
         for (int k = 0; k < NUM_COUNTERS; ++k) {
-            if (k == 10 || k == 11) ctr[k] = ag.ctr[k] > ctr[k] ? ag.ctr[k] : ctr[k];
-            else if (ag.ctr[k]) ctr[k] += ag.ctr[k];
+            if (k == 10 || k == 11 || k == 21) ctr[k] = s.ctr[k] > ctr[k] ? s.ctr[k] : ctr[k];
+            else if (s.ctr[k]) ctr[k] += s.ctr[k];
         }
         if (expanded_new) atomicAdd(&a.status->expansions, 1ull);
     }
@@ -799,7 +914,7 @@ static_assert(PRED_CHUNKS == 2, "selection code addresses prediction chunks 0 an
 // (c, agent) among candidates with c < best (strict; cross-tree ties -> lowest agent, which the
 // reference leaves to rayon), then wave 0 replays the winner's ActionSet from its root and
 // recomputes the cost (:226-241).
-template <int KW>
+template <int KW, bool BIG>
 __global__ __launch_bounds__(1024) void k_argmin(Arenas a, int init_mode) {
     __shared__ unsigned long long s_best[17];
     __shared__ WaveLds s;
@@ -854,7 +969,7 @@ __global__ __launch_bounds__(1024) void k_argmin(Arenas a, int init_mode) {
         }
     }
     ArgminRec *out = a.argmin;
-    double lam = lambda1_wave(s, n);
+    double lam = lambda1_wave<true>(pack_tree(s, n), n);
     int mu = matching_wave(s, n, out->matching);
     float ev = c21_eval(a.eval_slope, lam, mu);
     if (LANE < 32) out->parents[LANE] = LANE < n ? s.par[LANE] : 0;
@@ -939,50 +1054,76 @@ __global__ void k_probe_math(const float *in, float *out, int n) {
     out[4 * i + 3] = x - g;
 }
 
+// lambda_1 / matching probe: one wave per tree, `reps` repetitions (timing), result of the last one
+__global__ __launch_bounds__(64) void k_probe_cost(const uint8_t *__restrict__ parents, int n, int count, int reps,
+                                                   int full, double *__restrict__ lam_out, int *__restrict__ mu_out) {
+    __shared__ WaveLds s;
+    const int t = blockIdx.x;
+    if (t >= count) return;
+    if (LANE < PARENTS_STRIDE) s.par[LANE] = LANE < n ? parents[(size_t)t * n + LANE] : 0;
+    WAVE_SYNC();
+    double lam = 0.0;
+    int mu = 0;
+    for (int r = 0; r < reps; ++r) {
+        const PackedTree pt = pack_tree(s, n);
+        lam = full ? lambda1_wave<true>(pt, n) : lambda1_wave<false>(pt, n);
+        mu = full ? matching_wave(s, n, nullptr) : matching_size_wave(pt, n);
+        WAVE_SYNC();
+    }
+    if (LANE == 0) {
+        lam_out[t] = lam;
+        mu_out[t] = mu;
+    }
+}
+
 // ---------------------------------------------------------------- launchers
-#define DISPATCH_KW(KWV, FN, ...)            \
-    switch (KWV) {                           \
-    case 1: FN<1>(__VA_ARGS__); break;       \
-    case 2: FN<2>(__VA_ARGS__); break;       \
-    case 3: FN<3>(__VA_ARGS__); break;       \
-    default: FN<4>(__VA_ARGS__); break;      \
+// BIG is a spare specialisation flag (n > 19); the kernels no longer depend on it
+#define DISPATCH_KW(A, FN, ...)                                   \
+    switch ((A).KW) {                                             \
+    case 1: FN<1, false>(__VA_ARGS__); break;                     \
+    case 2: FN<2, false>(__VA_ARGS__); break;                     \
+    case 3:                                                       \
+        if ((A).n > 19) FN<3, true>(__VA_ARGS__);                 \
+        else FN<3, false>(__VA_ARGS__);                           \
+        break;                                                    \
+    default: FN<4, true>(__VA_ARGS__); break;                     \
     }
 
-template <int KW>
+template <int KW, bool BIG>
 static void l_init_roots(const Arenas &a, const uint8_t *p, const uint64_t *m, hipStream_t st) {
-    k_init_roots<KW><<<dim3(a.B), dim3(64), dyn_lds_bytes(a.n), st>>>(a, p, m);
+    k_init_roots<KW, BIG><<<dim3(a.B), dim3(64), dyn_lds_bytes(a.n), st>>>(a, p, m);
 }
-template <int KW>
+template <int KW, bool BIG>
 static void l_add_actions(const Arenas &a, int root_mode, hipStream_t st) {
     k_add_actions<KW><<<dim3(a.B), dim3(64), dyn_lds_bytes(a.n), st>>>(a, root_mode);
 }
-template <int KW>
+template <int KW, bool BIG>
 static void l_rollout(const Arenas &a, const TolTable &tol, hipStream_t st) {
-    k_rollout<KW><<<dim3(a.B), dim3(64), dyn_lds_bytes(a.n), st>>>(a, tol);
+    k_rollout<KW, BIG><<<dim3(a.B), dim3(64), dyn_lds_bytes(a.n), st>>>(a, tol);
 }
-template <int KW>
+template <int KW, bool BIG>
 static void l_argmin(const Arenas &a, int init_mode, hipStream_t st) {
-    k_argmin<KW><<<dim3(1), dim3(1024), dyn_lds_bytes(a.n), st>>>(a, init_mode);
+    k_argmin<KW, BIG><<<dim3(1), dim3(1024), dyn_lds_bytes(a.n), st>>>(a, init_mode);
 }
-template <int KW>
+template <int KW, bool BIG>
 static void l_observe(const Arenas &a, uint32_t tol, hipStream_t st) {
     k_observe<KW><<<dim3(a.B), dim3(64), dyn_lds_bytes(a.n), st>>>(a, tol);
 }
 
 void launch_init_roots(const Arenas &a, const uint8_t *d_parents, const uint64_t *d_permitted, void *stream) {
-    DISPATCH_KW(a.KW, l_init_roots, a, d_parents, d_permitted, (hipStream_t)stream);
+    DISPATCH_KW(a, l_init_roots, a, d_parents, d_permitted, (hipStream_t)stream);
 }
 void launch_add_actions(const Arenas &a, int root_mode, void *stream) {
-    DISPATCH_KW(a.KW, l_add_actions, a, root_mode, (hipStream_t)stream);
+    DISPATCH_KW(a, l_add_actions, a, root_mode, (hipStream_t)stream);
 }
 void launch_rollout(const Arenas &a, const TolTable &tol, void *stream) {
-    DISPATCH_KW(a.KW, l_rollout, a, tol, (hipStream_t)stream);
+    DISPATCH_KW(a, l_rollout, a, tol, (hipStream_t)stream);
 }
 void launch_argmin(const Arenas &a, int init_mode, void *stream) {
-    DISPATCH_KW(a.KW, l_argmin, a, init_mode, (hipStream_t)stream);
+    DISPATCH_KW(a, l_argmin, a, init_mode, (hipStream_t)stream);
 }
 void launch_observe(const Arenas &a, uint32_t n_obs_tol, void *stream) {
-    DISPATCH_KW(a.KW, l_observe, a, n_obs_tol, (hipStream_t)stream);
+    DISPATCH_KW(a, l_observe, a, n_obs_tol, (hipStream_t)stream);
 }
 void launch_hash_predictions(float *d_out, int batch, int action_dim, uint64_t seed, uint64_t first_agent,
                              uint64_t call, void *stream) {
@@ -991,6 +1132,10 @@ void launch_hash_predictions(float *d_out, int batch, int action_dim, uint64_t s
     int blocks = (int)((total + threads - 1) / threads);
     hipLaunchKernelGGL(k_hash_predictions, dim3(blocks), dim3(threads), 0, (hipStream_t)stream, d_out, batch, action_dim,
                        seed, first_agent, call);
+}
+void launch_probe_cost(const uint8_t *d_parents, int n, int count, int reps, int full, double *d_lam, int *d_mu,
+                       void *stream) {
+    k_probe_cost<<<dim3(count), dim3(64), dyn_lds_bytes(n), (hipStream_t)stream>>>(d_parents, n, count, reps, full, d_lam, d_mu);
 }
 void launch_probe_math(const float *d_in, float *d_out, int n, void *stream) {
     hipLaunchKernelGGL(k_probe_math, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, d_in, d_out, n);

@@ -162,7 +162,17 @@ enum { /* indices into azd_engine_counters' output */
     AZD_CTR_MAX_DEPTH = 11,
     AZD_CTR_CURIOSITY_PAIRS = 12,
     AZD_CTR_FAILED_AGENTS = 15,
-    AZD_CTR_COUNT = 16
+    /* 16..22: 100 MHz ticks per phase of the roll-out kernel, summed over agents; filled only by
+     * the diagnostic build (make PROFILE=1), 0 otherwise */
+    AZD_CTR_TICKS_TOTAL = 16,
+    AZD_CTR_TICKS_SELECT = 17,
+    AZD_CTR_TICKS_LOOKUP = 18,
+    AZD_CTR_TICKS_NEWNODE = 19,
+    AZD_CTR_TICKS_CASCADE = 20,
+    AZD_CTR_TICKS_MAX_CALL = 21, /* max over agents and calls of one agent's ticks in one call */
+    AZD_CTR_TICKS_LAMBDA = 22,   /* inside NEWNODE: lambda_1 */
+    AZD_CTR_TICKS_MATCHING = 23, /* inside NEWNODE: matching */
+    AZD_CTR_COUNT = 24
 };
 
 /* Allocates the device arenas.  `ev` may be NULL (external evaluator: drive the
@@ -233,6 +243,11 @@ void *azd_engine_stream(azd_engine *e); /* hipStream_t the engine launches on */
  * on bit-for-bit.  in: 2*n floats (pairs x, y); out: 4*n floats per pair:
  * [0] the kernels' sqrt(|x - y|), [1] sqrtf, [2] __fsqrt_rn (diagnostics), [3] x - (x - y). */
 int azd_debug_probe_math(int device, const float *in, float *out, int n);
+/* c21 cost kernel in isolation (ordered_edge.rs:72-124): lambda_1 (full = 1: full f64 bracket as
+ * ArgminData reports it; 0: the f32-exact early stop used for node costs) and the matching size of
+ * `count` trees, one wavefront each, repeated `reps` times; *ms = GPU time of the timed launch. */
+int azd_debug_probe_cost(int device, const uint8_t *parents, int n, int count, int reps, int full,
+                         double *lambda_1, int *matching_size, float *ms);
 
 #ifdef __cplusplus
 }

@@ -145,43 +145,60 @@ double lambda1_jacobi(const uint8_t *parents, int n) {
     return best;
 }
 
-/* Cost contract for lambda_1 (DESIGN.md "lambda_1"): the tree's adjacency
- * matrix A has parents[v] < v, so eliminating v = N-1 .. 0 in xI - A creates
- * no fill-in: pivot d_v = x - sum_{children c} 1/d_c.  xI - A is positive
- * definite  <=>  every pivot > 0  <=>  x > lambda_1.  Ten rounds of 64-way
- * multisection of [1, N] (all IEEE f64 +,-,*,/ with no fused ops) leave
- * hi - lo ~ 1 ulp; lambda_1 := hi, the smallest tested x that is positive
- * definite. */
+/* Cost contract for lambda_1 (DESIGN.md "lambda_1").  parents[v] < v, so the subtree T_v hangs
+ * below v.  With phi_v = characteristic polynomial of T_v and psi_v = prod_{children c} phi_c
+ * (that of T_v - v):   phi_v = x psi_v - sum_c psi_c prod_{c' != c} phi_c'.
+ * xI - A is positive definite  <=>  every phi_v(x) > 0  <=>  x > lambda_1 (the pivots of the
+ * leaf-first LDL^T are phi_v / psi_v).  Division-free: each vertex folds itself into its parent's
+ * running pair (P, Q) = (prod phi_c, sum_c psi_c prod_{c' != c} phi_c'):
+ *     phi = x P[v] - Q[v];  Q[p] = Q[p] phi + P[p] P[v];  P[p] = P[p] phi      (v = N-1 .. 1)
+ * every operation a single IEEE f64 multiply / add / subtract (no fused ops).  Ten rounds of
+ * 64-way multisection of [1, N] leave hi - lo ~ 1 ulp; lambda_1 := hi, the smallest tested x
+ * that is positive definite. */
 inline bool posdef_at(const uint8_t *parents, int n, double x) {
-    double acc[MAXN];
-    for (int v = 0; v < n; ++v) acc[v] = 0.0;
+    double P[MAXN], Q[MAXN];
+    for (int v = 0; v < n; ++v) {
+        P[v] = 1.0;
+        Q[v] = 0.0;
+    }
     bool ok = true;
     for (int v = n - 1; v >= 1; --v) {
-        double d = x - acc[v];
-        if (!(d > 0.0)) ok = false;
-        acc[parents[v]] = acc[parents[v]] + 1.0 / d;
+        double xp = x * P[v];
+        double phi = xp - Q[v];
+        if (!(phi > 0.0)) ok = false;
+        int p = parents[v];
+        double qphi = Q[p] * phi;
+        double ppsi = P[p] * P[v];
+        Q[p] = qphi + ppsi;
+        P[p] = P[p] * phi;
     }
-    double d0 = x - acc[0];
-    if (!(d0 > 0.0)) ok = false;
+    double xp0 = x * P[0];
+    double phi0 = xp0 - Q[0];
+    if (!(phi0 > 0.0)) ok = false;
     return ok;
 }
-double lambda1_sturm(const uint8_t *parents, int n) {
+/* 32 trial points per round (33-section of [lo, hi]), at most 12 rounds (33^12 > 2^60).
+ * node_mode: stop as soon as both ends of the bracket round to the same f32 -- the f32 value the
+ * evaluation uses (04-c21-tree.rs:100 `*lambda_1 as f32`) is then already the one the full-precision
+ * bracket would give, so tree topology cannot depend on the early stop.  Returns hi. */
+double lambda1_sturm(const uint8_t *parents, int n, bool node_mode) {
     double lo = 1.0, hi = (double)n;
-    for (int round = 0; round < 10; ++round) {
-        double w = (hi - lo) / 65.0;
-        int first = 64;
-        double xs[64];
-        for (int j = 0; j < 64; ++j) {
+    for (int round = 0; round < 12; ++round) {
+        if (node_mode && (float)lo == (float)hi) break;
+        double w = (hi - lo) / 33.0;
+        int first = 32;
+        double xs[32];
+        for (int j = 0; j < 32; ++j) {
             double step = w * (double)(j + 1);
             xs[j] = lo + step;
         }
-        for (int j = 0; j < 64; ++j)
+        for (int j = 0; j < 32; ++j)
             if (posdef_at(parents, n, xs[j])) {
                 first = j;
                 break;
             }
         double nlo = first > 0 ? xs[first - 1] : lo;
-        double nhi = first < 64 ? xs[first] : hi;
+        double nhi = first < 32 ? xs[first] : hi;
         lo = nlo;
         hi = nhi;
     }
@@ -263,9 +280,11 @@ struct Space { /* ROTModifyParentsOnce<N, Conjecture2Dot1Cost>, space.rs:14-125 
         for (uint32_t a : s.permitted) v[A + a] = 1.f;
     }
     /* space.rs:103-105 + ordered_edge.rs:72-82 */
-    Cost cost(const State &s) const {
+    /* full = false: node costs during the search (f32-exact early stop);
+     * full = true: the ArgminData cost reported to the user (full f64 bracket) */
+    Cost cost(const State &s, bool full = false) const {
         Cost c;
-        c.lambda1 = lambda1_sturm(s.parents, n);
+        c.lambda1 = lambda1_sturm(s.parents, n, !full);
         maximum_matching(s.parents, n, c.matching);
         return c;
     }
@@ -617,7 +636,7 @@ int update_argmin(orc_engine *e) {
             for (uint32_t a : kv.first) e->space.act(e->argmin_state, (int)a);
             break;
         }
-    e->argmin_cost = e->space.cost(e->argmin_state);
+    e->argmin_cost = e->space.cost(e->argmin_state, true);
     e->argmin_eval = e->space.evaluate(e->argmin_cost);
     return 1;
 }
@@ -650,7 +669,8 @@ int orc_all_possible_parent_modifications(const uint8_t *parents, int n, int *ou
     return cnt;
 }
 double orc_lambda1_jacobi(const uint8_t *parents, int n) { return lambda1_jacobi(parents, n); }
-double orc_lambda1_sturm(const uint8_t *parents, int n) { return lambda1_sturm(parents, n); }
+double orc_lambda1_sturm(const uint8_t *parents, int n) { return lambda1_sturm(parents, n, false); }
+double orc_lambda1_node(const uint8_t *parents, int n) { return lambda1_sturm(parents, n, true); }
 int orc_maximum_matching(const uint8_t *parents, int n, int *out_pairs) {
     std::vector<std::pair<int, int>> m;
     maximum_matching(parents, n, m);
@@ -774,7 +794,7 @@ void orc_new_end(orc_engine *e, const float *h) {
         if (ev < be) { be = ev; best = i; }
     }
     e->argmin_state = e->states[best];
-    e->argmin_cost = e->costs[best];
+    e->argmin_cost = sp.cost(e->states[best], true);
     e->argmin_eval = be;
 }
 

@@ -46,7 +46,8 @@ void orc_action_from_index(int index, int *parent, int *child); /* :40-42 */
 /* ordered_edge.rs:52-70; writes (parent, child) pairs, returns count */
 int orc_all_possible_parent_modifications(const uint8_t *parents, int n, int *out_pairs);
 double orc_lambda1_jacobi(const uint8_t *parents, int n);  /* dense symmetric eigen-solve (what faer does) */
-double orc_lambda1_sturm(const uint8_t *parents, int n);   /* tree LDL^T multisection (cost contract) */
+double orc_lambda1_sturm(const uint8_t *parents, int n);   /* cost contract, full f64 bracket (ArgminData) */
+double orc_lambda1_node(const uint8_t *parents, int n);    /* cost contract, f32-exact early stop (node costs) */
 int orc_maximum_matching(const uint8_t *parents, int n, int *out_pairs); /* ordered_edge.rs:94-124 */
 float orc_c21_eval(int n, double lambda1, int matching_size);           /* 04-c21-tree.rs:58-74,98-102 */
 

@@ -103,29 +103,37 @@ def write_vec(n, parents, permitted):  # space.rs:91-101
 
 
 def posdef(parents, n, x):
-    acc = [0.0] * n
+    # division-free subtree characteristic polynomials (DESIGN.md "lambda_1"): phi_v > 0 for all v
+    P = [1.0] * n
+    Q = [0.0] * n
     ok = True
     for v in range(n - 1, 0, -1):
-        d = x - acc[v]
-        if not d > 0.0:
+        phi = x * P[v] - Q[v]
+        if not phi > 0.0:
             ok = False
-        acc[parents[v]] = acc[parents[v]] + (1.0 / d if d != 0.0 else float("inf"))
-    if not (x - acc[0]) > 0.0:
+        p = parents[v]
+        Q[p] = Q[p] * phi + P[p] * P[v]
+        P[p] = P[p] * phi
+    if not (x * P[0] - Q[0]) > 0.0:
         ok = False
     return ok
 
 
-def lambda1(parents, n):  # cost contract for lambda_1: 10 rounds of 64-way multisection of [1, N]
+def lambda1(parents, n, node_mode=False):
+    """cost contract for lambda_1: 33-section of [1, N], <= 12 rounds; node_mode stops as
+    soon as both bracket ends round to the same f32 (what the evaluation uses)"""
     lo, hi = 1.0, float(n)
-    for _ in range(10):
-        w = (hi - lo) / 65.0
-        xs = [lo + w * float(j + 1) for j in range(64)]
-        first = 64
-        for j in range(64):
+    for _ in range(12):
+        if node_mode and F(lo) == F(hi):
+            break
+        w = (hi - lo) / 33.0
+        xs = [lo + w * float(j + 1) for j in range(32)]
+        first = 32
+        for j in range(32):
             if posdef(parents, n, xs[j]):
                 first = j
                 break
-        lo, hi = (xs[first - 1] if first > 0 else lo), (xs[first] if first < 64 else hi)
+        lo, hi = (xs[first - 1] if first > 0 else lo), (xs[first] if first < 32 else hi)
     return hi
 
 
@@ -159,8 +167,8 @@ def evaluate(n, lam, mu):  # 04-c21-tree.rs:58-74,98-102
     return slope * ((F(mu) + F(lam)) - F(2))
 
 
-def cost_eval(n, parents):
-    lam = lambda1(parents, n)
+def cost_eval(n, parents, full=False):
+    lam = lambda1(parents, n, node_mode=not full)
     mu = matching_size(parents, n)
     return lam, mu, evaluate(n, lam, mu)
 
@@ -289,8 +297,9 @@ class PyEngine:
     def new_end(self, h):
         self.trees = [self._root_tree(i, h[i]) for i in range(self.B)]
         best = min(range(self.B), key=lambda i: (self.costs[i][2], i))
+        lam, mu, _ = cost_eval(self.n, self.states[best][0], full=True)
         self.argmin = dict(parents=list(self.states[best][0]), permitted=set(self.states[best][1]),
-                           lambda1=self.costs[best][0], matching=self.costs[best][1], eval=self.costs[best][2])
+                           lambda1=lam, matching=mu, eval=self.costs[best][2])
 
     def _step(self, i, tol, tol_default):
         t, n = self.trees[i], self.n
@@ -359,7 +368,7 @@ class PyEngine:
         key = next(k for k, v in self.trees[i].pos.items() if v == j)
         for a in sorted(key):
             act(parents, permitted, a)
-        lam, mu, ev = cost_eval(self.n, parents)
+        lam, mu, ev = cost_eval(self.n, parents, full=True)
         self.argmin = dict(parents=parents, permitted=permitted, lambda1=lam, matching=mu, eval=ev)
         return 1
 

@@ -102,6 +102,9 @@ def test_lambda1_contract_vs_dense(orc):
             assert abs(lam_s - lam_np) < 1e-13 * n
             assert abs(lam_j - lam_np) < 1e-13 * n
             assert lam_s == po.lambda1([int(x) for x in parents], n)  # bit-identical f64
+            lam_n = L.orc_lambda1_node(_pv(parents), n)
+            assert lam_n == po.lambda1([int(x) for x in parents], n, node_mode=True)
+            assert np.float32(lam_n) == np.float32(lam_s)  # the early stop never changes the f32 the search uses
             flips += int(np.float32(lam_s) != np.float32(lam_np))
     assert flips == 0  # f32 rounding agrees with LAPACK on this sample
 
