@@ -17,6 +17,7 @@ CTR = dict(EXPANSIONS=0, TERMINALS=1, TRANSPOSITIONS=2, VISITED_STEPS=3, SELECT_
 CTR_COUNT = 24
 
 ACT_NONE, ACT_RELU, ACT_SIGMOID = 0, 1, 2
+ENGINE_NO_PERSISTENT_STEP = 1
 SPACE_C21 = 1
 
 
@@ -36,7 +37,7 @@ class AdamConfig(C.Structure):  # dfdx AdamConfig as set at 04-c21-tree.rs:87-92
 class EngineConfig(C.Structure):
     _fields_ = [("space_id", C.c_int), ("n", C.c_int), ("batch", C.c_int), ("device", C.c_int),
                 ("node_capacity", C.c_int), ("arc_capacity", C.c_int), ("prediction_capacity", C.c_int),
-                ("first_agent", C.c_uint64)]
+                ("first_agent", C.c_uint64), ("flags", C.c_uint32)]
 
 
 class Argmin(C.Structure):  # ArgminData<State, Cost>, az-discrete-opt/src/log.rs:1-11

@@ -50,6 +50,11 @@ struct TrivialEvaluator : azd_evaluator { // TrivialModel, model/mod.rs:10-23
         if (loss) *loss = 0.f;
         return AZD_OK;
     }
+    bool fused_desc(FusedEval *f) override {
+        memset(f, 0, sizeof(*f));
+        f->kind = 1;
+        return true;
+    }
 };
 
 struct HashStreamEvaluator : azd_evaluator {
@@ -59,6 +64,14 @@ struct HashStreamEvaluator : azd_evaluator {
         calls += 1;
         AZD_HIP(hipGetLastError());
         return AZD_OK;
+    }
+    bool fused_desc(FusedEval *f) override {
+        memset(f, 0, sizeof(*f));
+        f->kind = 2;
+        f->seed = seed;
+        f->first_agent = first_agent;
+        f->call_base = calls;
+        return true;
     }
     int update_model_dev(int, const float *, const float *, const float *, float *loss, hipStream_t) override {
         if (loss) *loss = 0.f;
@@ -112,6 +125,11 @@ struct azd_engine {
     std::vector<hipEvent_t> ev_pool;
     std::vector<std::pair<int, std::pair<hipEvent_t, hipEvent_t>>> ev_inflight; // kind 0 rollout, 1 evaluator
     bool initialised = false;
+    // persistent (CU-resident) step
+    bool persist_enabled = true;
+    unsigned long long *d_log_key = nullptr;
+    uint32_t *d_log_node = nullptr;
+    int log_calls = 0;
 
     template <typename T>
     int alloc(T **p, size_t count) {
@@ -436,6 +454,13 @@ int azd_engine_create(azd_engine **out, const azd_engine_config *cfg, azd_evalua
     TRY(e->alloc(&a.weights, B * a.A));
     TRY(e->alloc(&a.argmin, 1));
     TRY(e->alloc(&a.status, 1));
+    e->persist_enabled = (cfg->flags & AZD_ENGINE_NO_PERSISTENT_STEP) == 0;
+    e->log_calls = 1024;
+    {
+        const size_t n_wg = (B + 15) / 16;
+        TRY(e->alloc(&e->d_log_key, (size_t)e->log_calls * n_wg));
+        TRY(e->alloc(&e->d_log_node, (size_t)e->log_calls * n_wg));
+    }
     TRY(e->alloc(&e->d_stage_parents, B * a.n));
     TRY(e->alloc(&e->d_stage_perm, B * a.KW));
     {
@@ -551,14 +576,32 @@ int azd_engine_par_roll_out_episodes(azd_engine *e, const uint32_t *tol, int n_t
     azd::TolTable t;
     int st = fill_tol(t, tol, n_tol, dflt);
     if (st) return st;
-    for (int c = 0; c < n_calls; ++c) {
-        e->time_begin(0);
-        azd::launch_rollout(e->a, t, e->stream);
-        e->time_end();
-        st = run_evaluator(e); // :175-176
-        if (st) return st;
-        azd::launch_add_actions(e->a, 0, e->stream);
-        azd::launch_argmin(e->a, 0, e->stream); // :190
+    azd::FusedEval fe;
+    uint32_t dyn_stride = 0;
+    size_t dyn_bytes = 0;
+    if (e->persist_enabled && e->ev->fused_desc(&fe) && azd::persist_plan(e->a, fe, &dyn_stride, &dyn_bytes)) {
+        // CU-resident form: the whole call chain, n_calls times, in one launch per <= log_calls calls
+        int left = n_calls;
+        while (left > 0) {
+            const int k = left < e->log_calls ? left : e->log_calls;
+            e->ev->fused_desc(&fe); // refresh call_base
+            e->time_begin(0);
+            azd::launch_persist(e->a, t, fe, k, e->d_log_key, e->d_log_node, dyn_stride, dyn_bytes, e->stream);
+            e->time_end();
+            e->ev->calls += (uint64_t)k;
+            left -= k;
+        }
+        AZD_HIP(hipGetLastError());
+    } else {
+        for (int c = 0; c < n_calls; ++c) {
+            e->time_begin(0);
+            azd::launch_rollout(e->a, t, e->stream);
+            e->time_end();
+            st = run_evaluator(e); // :175-176
+            if (st) return st;
+            azd::launch_add_actions(e->a, 0, e->stream);
+            azd::launch_argmin(e->a, 0, e->stream); // :190
+        }
     }
     st = sync_status(e);
     if (improved) *improved = (int)(e->h_status->improved - e->seen_improved);

@@ -11,6 +11,7 @@
 //   ht     [B][ht_cap]         u32             open-addressing transposition table over `keys`
 //                                              (stands in for BTreeMap<P, NodeIndex>, tree/mod.rs:29)
 #pragma once
+#include <stddef.h>
 #include <stdint.h>
 
 namespace azd {
@@ -113,6 +114,18 @@ struct Arenas {
     float eval_slope;       // squish slope 1/(C_UPPER - C_LOWER), 04-c21-tree.rs:58-74
 };
 
+// what the persistent step needs to run the evaluator inside the kernel
+struct FusedEval {
+    int kind;                // 0 not fusable (external), 1 TrivialModel, 2 hash stream, 3 MLP
+    uint64_t seed, first_agent, call_base; // hash stream
+    const float *params;     // MLP: flat parameters (per layer W[out][in] then b[out])
+    int n_layers;
+    int dims[8];
+    int final_act;
+    int max_hidden;
+    long long w_off[7], b_off[7];
+};
+
 struct TolTable {
     uint32_t tol[MAX_TOL];
     int n_tol;
@@ -125,6 +138,9 @@ void launch_add_actions(const Arenas &a, int root_mode, void *stream);
 void launch_rollout(const Arenas &a, const TolTable &tol, void *stream);
 void launch_argmin(const Arenas &a, int init_mode, void *stream);
 void launch_observe(const Arenas &a, uint32_t n_obs_tol, void *stream);
+bool persist_plan(const Arenas &a, const FusedEval &ev, uint32_t *dyn_stride, size_t *dyn_bytes);
+void launch_persist(const Arenas &a, const TolTable &tol, const FusedEval &ev, int n_calls, unsigned long long *log_key,
+                    uint32_t *log_node, uint32_t dyn_stride, size_t dyn_bytes, void *stream);
 void launch_hash_predictions(float *d_out, int batch, int action_dim, uint64_t seed, uint64_t first_agent,
                              uint64_t call, void *stream);
 void launch_probe_cost(const uint8_t *d_parents, int n, int count, int reps, int full, double *d_lam, int *d_mu,

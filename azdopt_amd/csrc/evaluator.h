@@ -6,6 +6,7 @@
 #include <string>
 
 #include "../../include/azdopt_amd.h"
+#include "engine_types.h"
 
 namespace azd {
 
@@ -36,6 +37,8 @@ struct azd_evaluator {
     // NablaModel::update_model on device pointers; *loss is a host float, valid on return
     virtual int update_model_dev(int batch, const float *d_s, const float *d_o, const float *d_w, float *loss,
                                  hipStream_t st) = 0;
+    // description for the persistent step (evaluator inside the kernel); false = not fusable
+    virtual bool fused_desc(azd::FusedEval *) { return false; }
     virtual int64_t num_params() { return 0; }
     virtual int get_params(float *) { return AZD_ERR_UNSUPPORTED; }
     virtual int set_params(const float *) { return AZD_ERR_UNSUPPORTED; }

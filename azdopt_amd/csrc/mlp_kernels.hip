@@ -12,6 +12,7 @@
 #include <hip/hip_runtime.h>
 
 #include <cmath>
+#include <cstring>
 #include <new>
 #include <vector>
 
@@ -339,6 +340,25 @@ struct MlpEvaluator : azd_evaluator {
         return AZD_OK;
     }
 
+    bool fused_desc(FusedEval *f) override {
+        memset(f, 0, sizeof(*f));
+        if (L > 7) return false;
+        f->kind = 3;
+        f->params = d_params;
+        f->n_layers = L;
+        f->final_act = final_act;
+        int mh = 4;
+        for (int l = 0; l <= L; ++l) f->dims[l] = dims[(size_t)l];
+        for (int l = 0; l < L; ++l) {
+            // the in-kernel GEMM streams float4 along K: inputs in multiples of 16, rows 16-B aligned
+            if (dims[(size_t)l] % 16 != 0 || w_off[(size_t)l] % 4 != 0) return false;
+            f->w_off[l] = w_off[(size_t)l];
+            f->b_off[l] = b_off[(size_t)l];
+            if (l >= 1 && dims[(size_t)l] > mh) mh = dims[(size_t)l];
+        }
+        f->max_hidden = mh;
+        return true;
+    }
     int64_t num_params() override { return n_params; }
     int get_params(float *out) override {
         AZD_HIP(hipSetDevice(device));

@@ -141,11 +141,12 @@ struct WaveLds {
 };
 // views of the dynamic region
 extern __shared__ double azd_dyn_lds[];
-__device__ __forceinline__ float *lds_kids() { return (float *)azd_dyn_lds; } // [MAX_NODE_ACTIONS] c_star, newest arc first
-__device__ __forceinline__ uint32_t *lds_tmp_arc() { return (uint32_t *)azd_dyn_lds + MAX_NODE_ACTIONS; }
-__device__ __forceinline__ uint32_t *lds_fr_id() { return (uint32_t *)azd_dyn_lds; }                 // [2][FRONTIER_CAP]
-__device__ __forceinline__ uint32_t *lds_fr_x() { return (uint32_t *)azd_dyn_lds + 2 * FRONTIER_CAP; } // [2][FRONTIER_CAP]
-__device__ __forceinline__ double *lds_pq() { return azd_dyn_lds; } // [2][n-2][32] lambda_1 (P, Q) columns
+__device__ __forceinline__ char *lds_base(uint32_t dyn) { return (char *)azd_dyn_lds + dyn; } // dyn: byte offset of this wave's region
+__device__ __forceinline__ float *lds_kids(uint32_t dyn) { return (float *)lds_base(dyn); } // [MAX_NODE_ACTIONS] c_star, newest arc first
+__device__ __forceinline__ uint32_t *lds_tmp_arc(uint32_t dyn) { return (uint32_t *)lds_base(dyn) + MAX_NODE_ACTIONS; }
+__device__ __forceinline__ uint32_t *lds_fr_id(uint32_t dyn) { return (uint32_t *)lds_base(dyn); }                 // [2][FRONTIER_CAP]
+__device__ __forceinline__ uint32_t *lds_fr_x(uint32_t dyn) { return (uint32_t *)lds_base(dyn) + 2 * FRONTIER_CAP; } // [2][FRONTIER_CAP]
+__device__ __forceinline__ double *lds_pq(uint32_t dyn) { return (double *)lds_base(dyn); } // [2][n-2][32] lambda_1 (P, Q) columns
 static size_t dyn_lds_bytes(int n) {
     size_t fr = (size_t)4 * FRONTIER_CAP * sizeof(uint32_t);
     size_t sel = (size_t)2 * MAX_NODE_ACTIONS * sizeof(uint32_t);
@@ -241,11 +242,11 @@ __device__ __forceinline__ int matching_size_wave(const PackedTree &t, int n) {
 }
 
 template <bool FULL>
-__device__ double lambda1_wave(const PackedTree &t, int n) {
+__device__ double lambda1_wave(const PackedTree &t, int n, uint32_t dyn) {
     const uint64_t par0 = t.par0, par1 = t.par1;
     const int nslot = n > 2 ? n - 2 : 1;
     const int l = LANE & 31;
-    double *Pm = lds_pq() + l;
+    double *Pm = lds_pq(dyn) + l;
     double *Qm = Pm + nslot * 32;
     const int p_last = (int)(((n - 1) < 12 ? (par0 >> (5 * (n - 1))) : (par1 >> (5 * (n - 13)))) & 31ull);
     const int p_prev = (int)(((n - 2) < 12 ? (par0 >> (5 * (n - 2))) : (par1 >> (5 * (n - 14)))) & 31ull);
@@ -400,7 +401,7 @@ __device__ __forceinline__ bool node_active(const NodeRec &r) { return r.act_beg
 // cannot matter either because the merge is (min, +).  The propagated c_t_star never changes
 // along the sweep (every emitted Info carries the value it received), so it is one scalar.
 template <int KW>
-__device__ void cascade(const Arenas &a, Agent<KW> &ag, WaveLds &s, uint32_t src, uint32_t dst, bool old) {
+__device__ void cascade(const Arenas &a, Agent<KW> &ag, WaveLds &s, uint32_t dyn, uint32_t src, uint32_t dst, bool old) {
     NodeRec t = ag.nodes[dst];
     const uint32_t n_t_target = t.n_t;
     const float c = t.c_star;
@@ -408,8 +409,8 @@ __device__ void cascade(const Arenas &a, Agent<KW> &ag, WaveLds &s, uint32_t src
     int cur = 0;
     uint32_t n_cur = 1;
     if (LANE == 0) {
-        lds_fr_id()[0] = src;
-        lds_fr_x()[0] = x0;
+        lds_fr_id(dyn)[0] = src;
+        lds_fr_x(dyn)[0] = x0;
     }
     WAVE_SYNC();
     while (n_cur != 0) {
@@ -417,8 +418,8 @@ __device__ void cascade(const Arenas &a, Agent<KW> &ag, WaveLds &s, uint32_t src
         const int nxt = cur ^ 1;
         CTR_MAX(10, n_cur);
         for (uint32_t i = 0; i < n_cur; ++i) {
-            uint32_t u = lds_fr_id()[cur * FRONTIER_CAP + i];
-            uint32_t x = lds_fr_x()[cur * FRONTIER_CAP + i];
+            uint32_t u = lds_fr_id(dyn)[cur * FRONTIER_CAP + i];
+            uint32_t x = lds_fr_x(dyn)[cur * FRONTIER_CAP + i];
             NodeRec r = ag.nodes[u];
             r.exhausted += x;
             if (r.c_star > c) r.c_star = c;
@@ -438,7 +439,7 @@ __device__ void cascade(const Arenas &a, Agent<KW> &ag, WaveLds &s, uint32_t src
                 int found = -1;
                 for (uint32_t base = 0; base < n_nxt; base += 64) {
                     uint32_t j = base + (uint32_t)LANE;
-                    bool hit = (j < n_nxt) && (lds_fr_id()[nxt * FRONTIER_CAP + j] == p);
+                    bool hit = (j < n_nxt) && (lds_fr_id(dyn)[nxt * FRONTIER_CAP + j] == p);
                     uint64_t m = __ballot(hit);
                     if (m) {
                         found = (int)base + first_lane(m);
@@ -446,15 +447,15 @@ __device__ void cascade(const Arenas &a, Agent<KW> &ag, WaveLds &s, uint32_t src
                     }
                 }
                 if (found >= 0) {
-                    if (LANE == 0) lds_fr_x()[nxt * FRONTIER_CAP + found] += up_x;
+                    if (LANE == 0) lds_fr_x(dyn)[nxt * FRONTIER_CAP + found] += up_x;
                 } else {
                     if (n_nxt >= FRONTIER_CAP) {
                         ag.flags |= FLAG_FRONTIER_CAP;
                         return;
                     }
                     if (LANE == 0) {
-                        lds_fr_id()[nxt * FRONTIER_CAP + n_nxt] = p;
-                        lds_fr_x()[nxt * FRONTIER_CAP + n_nxt] = up_x;
+                        lds_fr_id(dyn)[nxt * FRONTIER_CAP + n_nxt] = p;
+                        lds_fr_x(dyn)[nxt * FRONTIER_CAP + n_nxt] = up_x;
                     }
                     n_nxt += 1;
                 }
@@ -491,6 +492,7 @@ template <int KW, bool BIG>
 __global__ __launch_bounds__(64) void k_init_roots(Arenas a, const uint8_t *__restrict__ parents,
                                                    const uint64_t *__restrict__ permitted) {
     __shared__ WaveLds s;
+    const uint32_t dyn = 0;
     const int t = blockIdx.x;
     const int n = a.n, A = a.A;
     build_action_table(s, A);
@@ -513,7 +515,7 @@ __global__ __launch_bounds__(64) void k_init_roots(Arenas a, const uint8_t *__re
     WAVE_SYNC();
     // optimizer/mod.rs:63 costs = space.cost(root)
     const PackedTree pt = pack_tree(s, n);
-    double lam = lambda1_wave<false>(pt, n);
+    double lam = lambda1_wave<false>(pt, n, dyn);
     int mu = matching_size_wave(pt, n);
     float c = c21_eval(a.eval_slope, lam, mu);
     // SearchTree::clear + add_node(P::new(), StateWeight::new(c)) (optimizer/mod.rs:81-84, :353-356)
@@ -547,9 +549,7 @@ __global__ __launch_bounds__(64) void k_init_roots(Arenas a, const uint8_t *__re
 // root_mode = 1: par_new / par_reset_trees (every agent, node 0); 0: after a roll-out (agents
 // whose path is non-empty, optimizer/mod.rs:186).
 template <int KW>
-__global__ __launch_bounds__(64) void k_add_actions(Arenas a, int root_mode) {
-    __shared__ WaveLds s;
-    const int t = blockIdx.x;
+__device__ void add_actions_agent(const Arenas &a, WaveLds &s, const int t, const int root_mode) {
     if (a.flags[t] != 0) return;
     uint64_t perm[KW], path[KW];
 #pragma unroll
@@ -559,7 +559,6 @@ __global__ __launch_bounds__(64) void k_add_actions(Arenas a, int root_mode) {
     }
     if (!root_mode && mask_empty<KW>(path)) return;
     const int A = a.A;
-    build_action_table(s, A);
     if (LANE < PARENTS_STRIDE) s.par[LANE] = a.cur_parents[(size_t)t * PARENTS_STRIDE + LANE];
     WAVE_SYNC();
     uint64_t cur[KW], legal[KW];
@@ -603,12 +602,20 @@ __global__ __launch_bounds__(64) void k_add_actions(Arenas a, int root_mode) {
     }
 }
 
-// tree/mod.rs:113-232 roll_out_episodes for every agent (optimizer/mod.rs:159-174)
-template <int KW, bool BIG>
-__global__ __launch_bounds__(64) void k_rollout(Arenas a, TolTable tol) {
+template <int KW>
+__global__ __launch_bounds__(64) void k_add_actions(Arenas a, int root_mode) {
     __shared__ WaveLds s;
-    const int t = blockIdx.x;
-    if (a.flags[t] != 0) return;
+    build_action_table(s, a.A);
+    add_actions_agent<KW>(a, s, (int)blockIdx.x, root_mode);
+}
+
+// tree/mod.rs:113-232 roll_out_episodes for every agent (optimizer/mod.rs:159-174)
+// One agent's call, run by one wavefront.  `s` is the wave's LDS block (action tables already
+// built), `dyn` the byte offset of its scratch region.  Returns true iff the call ended on a new
+// non-terminal node (the agent needs a prediction row).
+template <int KW>
+__device__ bool rollout_agent(const Arenas &a, const TolTable &tol, WaveLds &s, const uint32_t dyn, const int t) {
+    if (a.flags[t] != 0) return false;
     const int n = a.n, A = a.A;
     Agent<KW> ag;
     ag.nodes = a.nodes + (size_t)t * a.node_cap;
@@ -625,7 +632,6 @@ __global__ __launch_bounds__(64) void k_rollout(Arenas a, TolTable tol) {
 #pragma unroll
     for (int k = LANE; k < NUM_COUNTERS; k += 64) s.ctr[k] = 0;
 
-    build_action_table(s, A);
     if (LANE < PARENTS_STRIDE) s.par[LANE] = a.cur_parents[(size_t)t * PARENTS_STRIDE + LANE];
     uint64_t perm[KW], path[KW];
 #pragma unroll
@@ -703,7 +709,7 @@ __global__ __launch_bounds__(64) void k_rollout(Arenas a, TolTable tol) {
                     uint32_t off = 0;
 #pragma unroll
                     for (int ch = 0; ch < PRED_CHUNKS; ++ch) {
-                        if (expd[ch]) lds_tmp_arc()[off + (uint32_t)__popcll(exp_mask[ch] & ((1ull << LANE) - 1ull))] = p[ch].arc;
+                        if (expd[ch]) lds_tmp_arc(dyn)[off + (uint32_t)__popcll(exp_mask[ch] & ((1ull << LANE) - 1ull))] = p[ch].arc;
                         off += (uint32_t)__popcll(exp_mask[ch]);
                     }
                     WAVE_SYNC();
@@ -711,8 +717,8 @@ __global__ __launch_bounds__(64) void k_rollout(Arenas a, TolTable tol) {
                     for (int ch = 0; ch < PRED_CHUNKS; ++ch) {
                         if (expd[ch]) {
                             uint32_t rank = 0;
-                            for (uint32_t j = 0; j < n_exp; ++j) rank += lds_tmp_arc()[j] > p[ch].arc ? 1u : 0u;
-                            lds_kids()[rank] = k_cstar[ch];
+                            for (uint32_t j = 0; j < n_exp; ++j) rank += lds_tmp_arc(dyn)[j] > p[ch].arc ? 1u : 0u;
+                            lds_kids(dyn)[rank] = k_cstar[ch];
                         }
                     }
                     WAVE_SYNC();
@@ -730,7 +736,7 @@ __global__ __launch_bounds__(64) void k_rollout(Arenas a, TolTable tol) {
                             key = ((uint64_t)(~ordf(v)) << 32) | (uint64_t)(0xFFFFFFFFu - idx);
                         } else {
                             float sum = 0.0f; // f32 sum, sequential, newest child first
-                            for (uint32_t j = 0; j < n_exp; ++j) sum = sum + azd_sqrt(fabsf(lds_kids()[j] - v));
+                            for (uint32_t j = 0; j < n_exp; ++j) sum = sum + azd_sqrt(fabsf(lds_kids(dyn)[j] - v));
                             // max_by: last maximum  ->  maximise (ord(sum), idx)
                             key = ((uint64_t)ordf(sum) << 32) | (uint64_t)idx;
                         }
@@ -800,7 +806,7 @@ __global__ __launch_bounds__(64) void k_rollout(Arenas a, TolTable tol) {
             add_arc<KW>(ag, pos, hit, sel_pp);
             WAVE_SYNC();
             const unsigned long long ph_c0 = PH_NOW();
-            cascade<KW>(a, ag, s, pos, hit, true);
+            cascade<KW>(a, ag, s, dyn, pos, hit, true);
             CTR_ADD(20, PH_NOW() - ph_c0);
             CTR_ADD(2, 1);
             reset_to_root = true;
@@ -818,7 +824,7 @@ __global__ __launch_bounds__(64) void k_rollout(Arenas a, TolTable tol) {
             do_act<KW>(s, perm, sel_aid);
             const unsigned long long ph_l0 = PH_NOW();
             const PackedTree pt = pack_tree(s, n);
-            cur_lambda = lambda1_wave<false>(pt, n);
+            cur_lambda = lambda1_wave<false>(pt, n, dyn);
             const unsigned long long ph_l1 = PH_NOW();
             cur_mu = matching_size_wave(pt, n);
             CTR_ADD(22, ph_l1 - ph_l0);
@@ -848,7 +854,7 @@ __global__ __launch_bounds__(64) void k_rollout(Arenas a, TolTable tol) {
             for (int w = 0; w < KW; ++w) legal[w] = perm[w] & ~cur[w];
             if (mask_empty<KW>(legal)) { // terminal: is_terminal, nabla/space/mod.rs:23-25
                 const unsigned long long ph_c0 = PH_NOW();
-                cascade<KW>(a, ag, s, pos, v, false);
+                cascade<KW>(a, ag, s, dyn, pos, v, false);
                 CTR_ADD(20, PH_NOW() - ph_c0);
                 CTR_ADD(1, 1);
                 reset_to_root = true;
@@ -904,10 +910,61 @@ __global__ __launch_bounds__(64) void k_rollout(Arenas a, TolTable tol) {
         }
         if (expanded_new) atomicAdd(&a.status->expansions, 1ull);
     }
+    return expanded_new;
+}
+
+template <int KW, bool BIG>
+__global__ __launch_bounds__(64) void k_rollout(Arenas a, TolTable tol) {
+    __shared__ WaveLds s;
+    build_action_table(s, a.A);
+    rollout_agent<KW>(a, tol, s, 0u, (int)blockIdx.x);
 }
 
 
 static_assert(PRED_CHUNKS == 2, "selection code addresses prediction chunks 0 and 1 explicitly");
+
+// optimizer/mod.rs:226-241: ArgminData.state = roots[tree] with the winner's ActionSet replayed
+// (acts commute, ascending order), cost recomputed at full precision.  One wave.
+template <int KW>
+__device__ void argmin_replay(const Arenas &a, WaveLds &s, const uint32_t dyn, const int wt, const uint32_t win_node,
+                              const int init_mode) {
+    const int n = a.n, A = a.A;
+    build_action_table(s, A);
+    if (LANE < PARENTS_STRIDE) s.par[LANE] = a.root_parents[(size_t)wt * PARENTS_STRIDE + LANE];
+    uint64_t perm[KW], key[KW];
+#pragma unroll
+    for (int w = 0; w < KW; ++w) {
+        perm[w] = a.root_perm[(size_t)wt * KW + w];
+        key[w] = a.keys[((size_t)wt * a.node_cap + win_node) * KW + w];
+    }
+    WAVE_SYNC();
+#pragma unroll
+    for (int w = 0; w < KW; ++w) {
+        uint64_t bits = key[w];
+        while (bits) {
+            int b = __ffsll((unsigned long long)bits) - 1;
+            bits &= bits - 1;
+            do_act<KW>(s, perm, (uint32_t)(w * 64 + b));
+        }
+    }
+    ArgminRec *out = a.argmin;
+    double lam = lambda1_wave<true>(pack_tree(s, n), n, dyn);
+    int mu = matching_wave(s, n, out->matching);
+    float ev = c21_eval(a.eval_slope, lam, mu);
+    if (LANE < 32) out->parents[LANE] = LANE < n ? s.par[LANE] : 0;
+    if (LANE == 0) {
+#pragma unroll
+        for (int w = 0; w < 4; ++w) out->permitted[w] = 0;
+#pragma unroll
+        for (int w = 0; w < KW; ++w) out->permitted[w] = perm[w];
+        out->lambda_1 = lam;
+        out->matching_size = mu;
+        out->eval = ev;
+        out->agent = wt;
+        out->node = win_node;
+        if (!init_mode) atomicAdd(&a.status->improved, 1ull);
+    }
+}
 
 // optimizer/mod.rs:194-246 par_update_argmmim_data (init_mode = 0) and the argmin of par_new
 // (:92-101, init_mode = 1).  One block: a strided scan over agents for the lexicographic min of
@@ -918,6 +975,7 @@ template <int KW, bool BIG>
 __global__ __launch_bounds__(1024) void k_argmin(Arenas a, int init_mode) {
     __shared__ unsigned long long s_best[17];
     __shared__ WaveLds s;
+    const uint32_t dyn = 0;
     const int tid = threadIdx.x;
     const float best_eval = init_mode ? __int_as_float(0x7f800000) : a.argmin->eval;
     unsigned long long mine = ~0ull;
@@ -949,42 +1007,7 @@ __global__ __launch_bounds__(1024) void k_argmin(Arenas a, int init_mode) {
     for (int t = tid; t < a.B; t += blockDim.x) a.cand_node[t] = NONE; // num_inspected_nodes = nodes.len()
     if (tid >= 64 || wt < 0) return;
     // ---- single wave from here on (WAVE_SYNC only)
-    const int n = a.n, A = a.A;
-    build_action_table(s, A);
-    if (LANE < PARENTS_STRIDE) s.par[LANE] = a.root_parents[(size_t)wt * PARENTS_STRIDE + LANE];
-    uint64_t perm[KW], key[KW];
-#pragma unroll
-    for (int w = 0; w < KW; ++w) {
-        perm[w] = a.root_perm[(size_t)wt * KW + w];
-        key[w] = a.keys[((size_t)wt * a.node_cap + win_node) * KW + w];
-    }
-    WAVE_SYNC();
-#pragma unroll
-    for (int w = 0; w < KW; ++w) {
-        uint64_t bits = key[w];
-        while (bits) {
-            int b = __ffsll((unsigned long long)bits) - 1;
-            bits &= bits - 1;
-            do_act<KW>(s, perm, (uint32_t)(w * 64 + b));
-        }
-    }
-    ArgminRec *out = a.argmin;
-    double lam = lambda1_wave<true>(pack_tree(s, n), n);
-    int mu = matching_wave(s, n, out->matching);
-    float ev = c21_eval(a.eval_slope, lam, mu);
-    if (LANE < 32) out->parents[LANE] = LANE < n ? s.par[LANE] : 0;
-    if (LANE == 0) {
-#pragma unroll
-        for (int w = 0; w < 4; ++w) out->permitted[w] = 0;
-#pragma unroll
-        for (int w = 0; w < KW; ++w) out->permitted[w] = perm[w];
-        out->lambda_1 = lam;
-        out->matching_size = mu;
-        out->eval = ev;
-        out->agent = wt;
-        out->node = win_node;
-        if (!init_mode) atomicAdd(&a.status->improved, 1ull);
-    }
+    argmin_replay<KW>(a, s, dyn, wt, win_node, init_mode);
 }
 
 // optimizer/mod.rs:262-278: state_vecs <- root vectors; obs/weights zeroed then filled by
@@ -1040,6 +1063,8 @@ __global__ void k_hash_predictions(float *out, int batch, int action_dim, uint64
     out[i] = (float)(r >> 40) * (1.0f / 16777216.0f);
 }
 
+#include "persistent_step.inc"
+
 // parity probe for the f32 primitives the selection rule depends on; four outputs per input pair:
 //   [0] the kernel's own sqrt(|x - y|) (azd_sqrt)   [1] sqrtf   [2] __fsqrt_rn   [3] x - (x - y)
 __global__ void k_probe_math(const float *in, float *out, int n) {
@@ -1058,6 +1083,7 @@ __global__ void k_probe_math(const float *in, float *out, int n) {
 __global__ __launch_bounds__(64) void k_probe_cost(const uint8_t *__restrict__ parents, int n, int count, int reps,
                                                    int full, double *__restrict__ lam_out, int *__restrict__ mu_out) {
     __shared__ WaveLds s;
+    const uint32_t dyn = 0;
     const int t = blockIdx.x;
     if (t >= count) return;
     if (LANE < PARENTS_STRIDE) s.par[LANE] = LANE < n ? parents[(size_t)t * n + LANE] : 0;
@@ -1066,7 +1092,7 @@ __global__ __launch_bounds__(64) void k_probe_cost(const uint8_t *__restrict__ p
     int mu = 0;
     for (int r = 0; r < reps; ++r) {
         const PackedTree pt = pack_tree(s, n);
-        lam = full ? lambda1_wave<true>(pt, n) : lambda1_wave<false>(pt, n);
+        lam = full ? lambda1_wave<true>(pt, n, dyn) : lambda1_wave<false>(pt, n, dyn);
         mu = full ? matching_wave(s, n, nullptr) : matching_size_wave(pt, n);
         WAVE_SYNC();
     }
@@ -1124,6 +1150,36 @@ void launch_argmin(const Arenas &a, int init_mode, void *stream) {
 }
 void launch_observe(const Arenas &a, uint32_t n_obs_tol, void *stream) {
     DISPATCH_KW(a, l_observe, a, n_obs_tol, (hipStream_t)stream);
+}
+template <int KW, bool BIG>
+static void l_persist(const Arenas &a, const TolTable &tol, const FusedEval &ev, int n_calls, unsigned long long *log_key,
+                      uint32_t *log_node, uint32_t dyn_stride, size_t dyn_bytes, hipStream_t st) {
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute((const void *)k_persist<KW>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 16 * 1024);
+        attr_set = true;
+    }
+    const int n_wg = (a.B + PERSIST_WAVES - 1) / PERSIST_WAVES;
+    k_persist<KW><<<dim3(n_wg), dim3(PERSIST_WAVES * 64), dyn_bytes, st>>>(a, tol, ev, n_calls, log_key, log_node, dyn_stride);
+    k_argmin_log<KW, BIG><<<dim3(1), dim3(64), dyn_lds_bytes(a.n), st>>>(a, n_calls, n_wg, log_key, log_node);
+}
+// LDS plan of the persistent step; returns false when the workgroup does not fit a CU
+bool persist_plan(const Arenas &a, const FusedEval &ev, uint32_t *dyn_stride, size_t *dyn_bytes) {
+    size_t stride = (dyn_lds_bytes(a.n) + 15) & ~(size_t)15;
+    size_t total = stride * PERSIST_WAVES;
+    if (ev.kind == 3) {
+        size_t mlp = (size_t)PERSIST_WAVES * ((size_t)(ev.dims[0] + 4) + 2 * (size_t)(ev.max_hidden + 4)) * sizeof(float);
+        if (mlp > total) total = mlp;
+    }
+    const size_t static_lds = PERSIST_WAVES * (sizeof(WaveLds) + 16) + 256;
+    if (total + static_lds > 160 * 1024) return false;
+    *dyn_stride = (uint32_t)stride;
+    *dyn_bytes = total;
+    return true;
+}
+void launch_persist(const Arenas &a, const TolTable &tol, const FusedEval &ev, int n_calls, unsigned long long *log_key,
+                    uint32_t *log_node, uint32_t dyn_stride, size_t dyn_bytes, void *stream) {
+    DISPATCH_KW(a, l_persist, a, tol, ev, n_calls, log_key, log_node, dyn_stride, dyn_bytes, (hipStream_t)stream);
 }
 void launch_hash_predictions(float *d_out, int batch, int action_dim, uint64_t seed, uint64_t first_agent,
                              uint64_t call, void *stream) {

@@ -133,7 +133,12 @@ typedef struct azd_engine_config {
     int arc_capacity;
     int prediction_capacity;
     uint64_t first_agent; /* global id of agent 0 (multi-GPU sharding) */
+    uint32_t flags;       /* AZD_ENGINE_* */
 } azd_engine_config;
+
+/* run every phase of a call as its own kernel launch instead of the CU-resident persistent step
+ * (the two forms produce identical trees; the persistent step is the fast one) */
+#define AZD_ENGINE_NO_PERSISTENT_STEP 1u
 
 /* ArgminData<State, Cost> (az-discrete-opt/src/log.rs:1-11) for the c21 space */
 typedef struct azd_argmin {

@@ -289,14 +289,16 @@ def test_mlp_update_matches_cpu_and_torch(az, orc):
         assert np.max(np.abs(pg - pt)) < 0.05 * cfg["lr"], it
 
 
-def test_topology_parity_with_mlp_predictions(az, orc):
-    """End-to-end with the real MLP: feed the GPU's own predictions to the oracle; trees must
-    match bit-for-bit (MLP parity is tolerance-checked separately)."""
-    n, B, seed = 19, 64, 4
+@pytest.mark.parametrize("persistent", [True, False])
+def test_topology_parity_with_mlp_predictions(az, orc, persistent):
+    """End-to-end with the real MLP (in-kernel MFMA evaluator of the persistent step, or the
+    launch-per-phase form): feed the GPU's own predictions to the oracle; trees must match
+    bit-for-bit (MLP parity is tolerance-checked separately)."""
+    n, B, seed = 19, 72, 4  # 72 = 4.5 workgroups of 16 agents: exercises the ragged last group
     space = az.ROTModifyParentsOnce(n)
     model = az.ActionModel(B, space.STATE_DIM, space.ACTION_DIM, hidden=(256, 256, 256), seed=seed)
     parents, permitted = space.generate_roots(seed, B)
-    opt = az.NablaOptimizer.par_new(space, (parents, permitted), model, B)
+    opt = az.NablaOptimizer.par_new(space, (parents, permitted), model, B, persistent=persistent)
     oe = orc.Engine(n, B, threads=8)
     oe.new_begin(parents, permitted)
     oe.new_end(opt.predictions())
@@ -309,3 +311,39 @@ def test_topology_parity_with_mlp_predictions(az, orc):
         assert_tree_equal(opt.get_tree(i), oe.export_tree(i), f"agent {i}")
     loss = opt.par_update_model(5)
     assert np.isfinite(loss)
+
+
+def test_persistent_step_equals_launch_per_phase(az, orc):
+    """The CU-resident persistent step and the launch-per-phase form are the same computation:
+    identical trees / counters / argmin with the fixed prediction stream (many calls per launch),
+    and in-kernel MLP rows within the MLP tolerance of the batched GEMM path."""
+    n, B, seed = 19, 200, 6
+    space = az.ROTModifyParentsOnce(n)
+    roots = space.generate_roots(seed, B)
+    opts = []
+    for persistent in (True, False):
+        model = az.HashStreamModel(space.STATE_DIM, space.ACTION_DIM, seed)
+        o = az.NablaOptimizer.par_new(space, roots, model, B, persistent=persistent)
+        imp = o.par_roll_out_episodes(TOL_REF, n_calls=150)
+        opts.append((o, imp, model))
+    (o1, i1, _), (o2, i2, _) = opts
+    assert i1 == i2
+    c1, c2 = o1.counters(), o2.counters()
+    for k in MAIN_CTRS:
+        assert c1[k] == c2[k], k
+    for i in range(B):
+        t1, t2 = o1.get_tree(i), o2.get_tree(i)
+        for f in t1.FIELDS:
+            a, b = getattr(t1, f), getattr(t2, f)
+            assert a.shape == b.shape and np.array_equal(a.view(np.uint32) if a.dtype.kind == "f" else a, b.view(np.uint32) if b.dtype.kind == "f" else b), (i, f)
+    a1, a2 = o1.argmin_data(), o2.argmin_data()
+    assert a1.eval == a2.eval and a1.agent == a2.agent and a1.node == a2.node
+    # MLP rows: same states, both evaluator forms
+    preds = []
+    for persistent in (True, False):
+        model = az.ActionModel(B, space.STATE_DIM, space.ACTION_DIM, hidden=(256, 256, 256), seed=2)
+        o = az.NablaOptimizer.par_new(space, roots, model, B, persistent=persistent)
+        o.par_roll_out_episodes(TOL_REF, n_calls=1)
+        preds.append((o.state_vecs(), o.predictions()))
+    assert np.array_equal(preds[0][0], preds[1][0])
+    assert np.max(np.abs(preds[0][1] - preds[1][1])) < MLP_ATOL
