@@ -678,6 +678,43 @@ int azd_engine_par_reset_trees(azd_engine *e, const uint8_t *parents, const uint
     return reset_finish(e);
 }
 
+// par_reset_trees with the c21 driver's modify_root policy (04-c21-tree.rs:172-206) evaluated on the
+// device: no host round trip at the epoch boundary.
+static int c21_policy_args_ok(azd_engine *e, int kmin, int kmax) {
+    if (!e || !e->initialised) return AZD_ERR_INVALID_ARGUMENT;
+    if (kmin < 1 || kmax < kmin || kmax > e->a.A || kmax > azd::MAX_NODE_ACTIONS) return AZD_ERR_INVALID_ARGUMENT;
+    return AZD_OK;
+}
+int azd_engine_par_reset_trees_c21(azd_engine *e, uint64_t seed, uint64_t epoch, int kmin, int kmax) {
+    int st = c21_policy_args_ok(e, kmin, kmax);
+    if (st) return st;
+    if (!e->ev) return AZD_ERR_NO_EVALUATOR;
+    AZD_HIP(hipSetDevice(e->cfg.device));
+    const azd::Arenas &a = e->a;
+    azd::launch_c21_modify_roots(a, seed, epoch, e->cfg.first_agent, kmin, kmax, e->d_stage_parents, e->d_stage_perm, e->stream);
+    AZD_HIP(hipMemsetAsync(&a.status->failed, 0, sizeof(unsigned long long), e->stream));
+    azd::launch_init_roots(a, e->d_stage_parents, e->d_stage_perm, e->stream);
+    AZD_HIP(hipMemsetAsync(a.h_theta, 0, (size_t)a.B * a.A * 4, e->stream));
+    AZD_HIP(hipGetLastError());
+    st = run_evaluator(e);
+    if (st) return st;
+    return reset_finish(e);
+}
+int azd_c21_modify_roots_dev(azd_engine *e, uint64_t seed, uint64_t epoch, int kmin, int kmax, uint8_t *parents_out,
+                             uint64_t *permitted_out) {
+    int st = c21_policy_args_ok(e, kmin, kmax);
+    if (st) return st;
+    if (!parents_out || !permitted_out) return AZD_ERR_INVALID_ARGUMENT;
+    AZD_HIP(hipSetDevice(e->cfg.device));
+    const azd::Arenas &a = e->a;
+    azd::launch_c21_modify_roots(a, seed, epoch, e->cfg.first_agent, kmin, kmax, e->d_stage_parents, e->d_stage_perm, e->stream);
+    AZD_HIP(hipMemcpyAsync(parents_out, e->d_stage_parents, (size_t)a.B * a.n, hipMemcpyDeviceToHost, e->stream));
+    AZD_HIP(hipMemcpyAsync(permitted_out, e->d_stage_perm, (size_t)a.B * a.KW * 8, hipMemcpyDeviceToHost, e->stream));
+    AZD_HIP(hipStreamSynchronize(e->stream));
+    AZD_HIP(hipGetLastError());
+    return AZD_OK;
+}
+
 int azd_engine_argmin_data(azd_engine *e, azd_argmin *out) {
     if (!e || !out || !e->initialised) return AZD_ERR_INVALID_ARGUMENT;
     AZD_HIP(hipSetDevice(e->cfg.device));

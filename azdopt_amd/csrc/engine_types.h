@@ -141,6 +141,8 @@ void launch_observe(const Arenas &a, uint32_t n_obs_tol, void *stream);
 bool persist_plan(const Arenas &a, const FusedEval &ev, uint32_t *dyn_stride, size_t *dyn_bytes);
 void launch_persist(const Arenas &a, const TolTable &tol, const FusedEval &ev, int n_calls, unsigned long long *log_key,
                     uint32_t *log_node, uint32_t dyn_stride, size_t dyn_bytes, void *stream);
+void launch_c21_modify_roots(const Arenas &a, uint64_t seed, uint64_t epoch, uint64_t first_agent, int kmin, int kmax,
+                             uint8_t *d_parents, uint64_t *d_perm, void *stream);
 void launch_hash_predictions(float *d_out, int batch, int action_dim, uint64_t seed, uint64_t first_agent,
                              uint64_t call, void *stream);
 void launch_probe_cost(const uint8_t *d_parents, int n, int count, int reps, int full, double *d_lam, int *d_mu,

@@ -1064,6 +1064,7 @@ __global__ void k_hash_predictions(float *out, int batch, int action_dim, uint64
 }
 
 #include "persistent_step.inc"
+#include "root_policy.inc"
 
 // parity probe for the f32 primitives the selection rule depends on; four outputs per input pair:
 //   [0] the kernel's own sqrt(|x - y|) (azd_sqrt)   [1] sqrtf   [2] __fsqrt_rn   [3] x - (x - y)
@@ -1180,6 +1181,15 @@ bool persist_plan(const Arenas &a, const FusedEval &ev, uint32_t *dyn_stride, si
 void launch_persist(const Arenas &a, const TolTable &tol, const FusedEval &ev, int n_calls, unsigned long long *log_key,
                     uint32_t *log_node, uint32_t dyn_stride, size_t dyn_bytes, void *stream) {
     DISPATCH_KW(a, l_persist, a, tol, ev, n_calls, log_key, log_node, dyn_stride, dyn_bytes, (hipStream_t)stream);
+}
+template <int KW, bool BIG>
+static void l_modify_roots(const Arenas &a, uint64_t seed, uint64_t epoch, uint64_t first_agent, int kmin, int kmax,
+                           uint8_t *d_parents, uint64_t *d_perm, hipStream_t st) {
+    k_c21_modify_roots<KW><<<dim3(a.B), dim3(64), dyn_lds_bytes(a.n), st>>>(a, seed, epoch, first_agent, kmin, kmax, d_parents, d_perm);
+}
+void launch_c21_modify_roots(const Arenas &a, uint64_t seed, uint64_t epoch, uint64_t first_agent, int kmin, int kmax,
+                             uint8_t *d_parents, uint64_t *d_perm, void *stream) {
+    DISPATCH_KW(a, l_modify_roots, a, seed, epoch, first_agent, kmin, kmax, d_parents, d_perm, (hipStream_t)stream);
 }
 void launch_hash_predictions(float *d_out, int batch, int action_dim, uint64_t seed, uint64_t first_agent,
                              uint64_t call, void *stream) {

@@ -93,16 +93,24 @@ class NablaOptimizer:
         parents, permitted = self._roots(*roots)
         _lib.check(self._L.azd_engine_par_reset_trees(self._h, _lib.ptr(parents), _lib.ptr(permitted)), "par_reset_trees")
 
-    def c21_modify_roots(self, seed, epoch, kmin=None, kmax=None):
-        """The driver's modify_root policy (04-c21-tree.rs:172-206), seeded."""
+    def c21_modify_roots(self, seed, epoch, kmin=None, kmax=None, device=True):
+        """The driver's modify_root policy (04-c21-tree.rs:172-206), seeded; evaluated by the device
+        kernel (default) or by the host C++ restatement on exported node data."""
         lo, hi = self.space.default_permitted_range()
         kmin = lo if kmin is None else kmin
         kmax = hi if kmax is None else kmax
         parents = np.zeros((self.batch, self.space.n), np.uint8)
         permitted = np.zeros((self.batch, self.space.KEY_WORDS), np.uint64)
-        _lib.check(self._L.azd_c21_modify_roots(self._h, seed, epoch, kmin, kmax, _lib.ptr(parents), _lib.ptr(permitted)),
-                   "azd_c21_modify_roots")
+        fn = self._L.azd_c21_modify_roots_dev if device else self._L.azd_c21_modify_roots
+        _lib.check(fn(self._h, seed, epoch, kmin, kmax, _lib.ptr(parents), _lib.ptr(permitted)), "azd_c21_modify_roots")
         return parents, permitted
+
+    def par_reset_trees_c21(self, seed, epoch, kmin=None, kmax=None):
+        """par_reset_trees with the c21 modify_root policy evaluated on the device (no host round trip)."""
+        lo, hi = self.space.default_permitted_range()
+        kmin = lo if kmin is None else kmin
+        kmax = hi if kmax is None else kmax
+        _lib.check(self._L.azd_engine_par_reset_trees_c21(self._h, seed, epoch, kmin, kmax), "par_reset_trees_c21")
 
     def argmin_data(self):
         """optimizer/mod.rs:361"""

@@ -86,7 +86,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=100)
     ap.add_argument("--cpu-steps", type=int, default=40)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--chunk", type=int, default=50, help="calls per host round trip")
+    ap.add_argument("--chunk", type=int, default=100, help="calls per host round trip")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -133,7 +133,7 @@ def main():
             gathered = allgather_training_triple(dist, torch, views, world)
             torch.cuda.synchronize()
             losses.append(model.update_model_dev(B_total, *[g.data_ptr() for g in gathered], stream=opt.stream()))
-        opt.par_reset_trees(opt.c21_modify_roots(SEED, epoch))
+        opt.par_reset_trees_c21(SEED, epoch)  # modify_root policy + reset on the device
         epoch += 1
 
     def run(n_calls):

@@ -207,6 +207,13 @@ int azd_engine_argmin_data(azd_engine *e, azd_argmin *out);
 int azd_c21_modify_roots(azd_engine *e, uint64_t seed, uint64_t epoch, int kmin, int kmax,
                          uint8_t *parents_out, uint64_t *permitted_out);
 
+/* The same policy evaluated on the device (one wavefront per tree, radix select of the chosen key
+ * in BTreeMap order): _dev returns the roots it would install, par_reset_trees_c21 = policy +
+ * par_reset_trees with no host round trip. */
+int azd_c21_modify_roots_dev(azd_engine *e, uint64_t seed, uint64_t epoch, int kmin, int kmax,
+                             uint8_t *parents_out, uint64_t *permitted_out);
+int azd_engine_par_reset_trees_c21(azd_engine *e, uint64_t seed, uint64_t epoch, int kmin, int kmax);
+
 /* Split-phase forms of the three calls above, cut at the model call
  * (optimizer/mod.rs:72, :175-176, :348), for an external NablaModel:
  * *_begin leaves the state vectors ready, *_end consumes h_theta (host, batch*action_dim). */

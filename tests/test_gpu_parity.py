@@ -108,10 +108,14 @@ def run_parity(az, orc, n, B, kmin, kmax, tol, steps, epochs, seed, n_obs_tol, c
         oo, ow = oe.observe(n_obs_tol)
         assert np.array_equal(obs.view(np.uint32), oo.view(np.uint32)) and np.array_equal(w, ow)
         assert np.array_equal(sv, oe.state_vecs())
-        rg = opt.c21_modify_roots(seed, epoch, kmin, kmax)
         ro = oe.modify_roots(seed, epoch, first_agent, kmin, kmax)
-        assert np.array_equal(rg[0], ro[0]) and np.array_equal(rg[1], ro[1])
-        opt.par_reset_trees(rg)
+        for device in (True, False):  # device kernel and host C++ restatement of the root policy
+            rg = opt.c21_modify_roots(seed, epoch, kmin, kmax, device=device)
+            assert np.array_equal(rg[0], ro[0]) and np.array_equal(rg[1], ro[1]), (epoch, device)
+        if epoch % 2 == 0:
+            opt.par_reset_trees_c21(seed, epoch, kmin, kmax)  # policy + reset without a host round trip
+        else:
+            opt.par_reset_trees(rg)
         oe.reset_begin(*ro)
         call += 1
         oe.reset_end(orc.hash_predictions(seed, first_agent, B, space.ACTION_DIM, call))
