@@ -127,6 +127,8 @@ struct azd_engine {
     bool initialised = false;
     // persistent (CU-resident) step
     bool persist_enabled = true;
+    azd::PersistArgs *d_pargs = nullptr;
+    azd::PersistArgs *h_pargs = nullptr; // pinned
     unsigned long long *d_log_key = nullptr;
     uint32_t *d_log_node = nullptr;
     int log_calls = 0;
@@ -458,6 +460,13 @@ int azd_engine_create(azd_engine **out, const azd_engine_config *cfg, azd_evalua
     e->log_calls = 1024;
     {
         const size_t n_wg = (B + 15) / 16;
+        TRY(e->alloc(&e->d_pargs, 1));
+        hipError_t he2 = hipHostMalloc((void **)&e->h_pargs, sizeof(azd::PersistArgs));
+        if (he2 != hipSuccess) {
+            st = azd::hip_fail(he2, "hipHostMalloc");
+            azd_engine_destroy(e);
+            return st;
+        }
         TRY(e->alloc(&e->d_log_key, (size_t)e->log_calls * n_wg));
         TRY(e->alloc(&e->d_log_node, (size_t)e->log_calls * n_wg));
     }
@@ -496,6 +505,7 @@ int azd_engine_destroy(azd_engine *e) {
     for (void *p : e->allocs) (void)hipFree(p);
     if (e->h_status) (void)hipHostFree(e->h_status);
     if (e->h_argmin) (void)hipHostFree(e->h_argmin);
+    if (e->h_pargs) (void)hipHostFree(e->h_pargs);
     for (auto &it : e->ev_inflight) {
         (void)hipEventDestroy(it.second.first);
         (void)hipEventDestroy(it.second.second);
@@ -585,8 +595,14 @@ int azd_engine_par_roll_out_episodes(azd_engine *e, const uint32_t *tol, int n_t
         while (left > 0) {
             const int k = left < e->log_calls ? left : e->log_calls;
             e->ev->fused_desc(&fe); // refresh call_base
+            // the pinned block may still be in flight from the previous launch's copy
+            AZD_HIP(hipStreamSynchronize(e->stream));
+            e->h_pargs->a = e->a;
+            e->h_pargs->tol = t;
+            e->h_pargs->ev = fe;
+            AZD_HIP(hipMemcpyAsync(e->d_pargs, e->h_pargs, sizeof(azd::PersistArgs), hipMemcpyHostToDevice, e->stream));
             e->time_begin(0);
-            azd::launch_persist(e->a, t, fe, k, e->d_log_key, e->d_log_node, dyn_stride, dyn_bytes, e->stream);
+            azd::launch_persist(e->a, e->d_pargs, k, e->d_log_key, e->d_log_node, dyn_stride, dyn_bytes, e->stream);
             e->time_end();
             e->ev->calls += (uint64_t)k;
             left -= k;

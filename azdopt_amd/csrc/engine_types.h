@@ -33,8 +33,8 @@ struct __attribute__((aligned(16))) NodeRec {
     uint32_t exhausted; // exhausted_children
     uint32_t act_begin; // actions: Range<u32> into preds
     uint32_t act_end;
-    uint32_t first_in;  // head of the incoming-arc list (newest first), NONE if empty
-    uint32_t pad;
+    uint32_t first_in;  // head of the list of LATER arcs into this node (transpositions), NONE if empty
+    uint32_t in_src;    // source of the arc that created the node (NONE for the root)
 };
 static_assert(sizeof(NodeRec) == 32, "NodeRec must be 32 B");
 
@@ -132,6 +132,12 @@ struct TolTable {
     uint32_t tol_default;
 };
 
+struct PersistArgs { // argument block of the persistent step, read from device memory
+    Arenas a;
+    TolTable tol;
+    FusedEval ev;
+};
+
 // kernel launchers (tree_kernels.hip); all asynchronous on `stream`
 void launch_init_roots(const Arenas &a, const uint8_t *d_parents, const uint64_t *d_permitted, void *stream);
 void launch_add_actions(const Arenas &a, int root_mode, void *stream);
@@ -139,7 +145,7 @@ void launch_rollout(const Arenas &a, const TolTable &tol, void *stream);
 void launch_argmin(const Arenas &a, int init_mode, void *stream);
 void launch_observe(const Arenas &a, uint32_t n_obs_tol, void *stream);
 bool persist_plan(const Arenas &a, const FusedEval &ev, uint32_t *dyn_stride, size_t *dyn_bytes);
-void launch_persist(const Arenas &a, const TolTable &tol, const FusedEval &ev, int n_calls, unsigned long long *log_key,
+void launch_persist(const Arenas &a, const PersistArgs *d_args, int n_calls, unsigned long long *log_key,
                     uint32_t *log_node, uint32_t dyn_stride, size_t dyn_bytes, void *stream);
 void launch_c21_modify_roots(const Arenas &a, uint64_t seed, uint64_t epoch, uint64_t first_agent, int kmin, int kmax,
                              uint8_t *d_parents, uint64_t *d_perm, void *stream);

@@ -60,29 +60,57 @@ __device__ __forceinline__ uint32_t ordf(float f) {
 // value rounded back to f32 is exact-rounded (53 >= 2*24 + 2 bits), independent of the f32 sqrt
 // expansion hipcc picks.
 __device__ __forceinline__ float azd_sqrt(float x) { return (float)sqrt((double)x); }
-__device__ __forceinline__ uint64_t wave_min_u64(uint64_t v) {
-#pragma unroll
-    for (int off = 32; off >= 1; off >>= 1) {
-        uint64_t o = __shfl_xor(v, off, 64);
-        v = o < v ? o : v;
-    }
-    return v;
-}
-__device__ __forceinline__ uint64_t wave_max_u64(uint64_t v) {
-#pragma unroll
-    for (int off = 32; off >= 1; off >>= 1) {
-        uint64_t o = __shfl_xor(v, off, 64);
-        v = o > v ? o : v;
-    }
-    return v;
+// Wave-wide reductions on the DPP cross-lane path (row_shr 1/2/4/8, row_bcast 15/31, then one
+// v_readlane): ~13 VALU ops per 32-bit reduction.  The __shfl_xor butterfly costs a dependent
+// ds_bpermute (an LDS-crossbar round trip) per step, 12 of them for a 64-bit key -- measured as the
+// largest single cost of a selection step.
+#define AZD_DPP_STEP(OP, ID, V, CTRL, ROWM, BANKM)                                                   \
+    do {                                                                                             \
+        uint32_t _t = (uint32_t)__builtin_amdgcn_update_dpp((int)(ID), (int)(V), CTRL, ROWM, BANKM, false); \
+        V = OP(V, _t);                                                                               \
+    } while (0)
+__device__ __forceinline__ uint32_t u32_min(uint32_t a, uint32_t b) { return a < b ? a : b; }
+__device__ __forceinline__ uint32_t u32_max(uint32_t a, uint32_t b) { return a > b ? a : b; }
+__device__ __forceinline__ uint32_t u32_or(uint32_t a, uint32_t b) { return a | b; }
+__device__ __forceinline__ uint32_t wave_min_u32(uint32_t v) {
+    AZD_DPP_STEP(u32_min, 0xFFFFFFFFu, v, 0x111, 0xf, 0xf);
+    AZD_DPP_STEP(u32_min, 0xFFFFFFFFu, v, 0x112, 0xf, 0xf);
+    AZD_DPP_STEP(u32_min, 0xFFFFFFFFu, v, 0x114, 0xf, 0xe);
+    AZD_DPP_STEP(u32_min, 0xFFFFFFFFu, v, 0x118, 0xf, 0xc);
+    AZD_DPP_STEP(u32_min, 0xFFFFFFFFu, v, 0x142, 0xa, 0xf);
+    AZD_DPP_STEP(u32_min, 0xFFFFFFFFu, v, 0x143, 0xc, 0xf);
+    return (uint32_t)__builtin_amdgcn_readlane((int)v, 63);
 }
 __device__ __forceinline__ uint32_t wave_max_u32(uint32_t v) {
-#pragma unroll
-    for (int off = 32; off >= 1; off >>= 1) {
-        uint32_t o = __shfl_xor(v, off, 64);
-        v = o > v ? o : v;
-    }
-    return v;
+    AZD_DPP_STEP(u32_max, 0u, v, 0x111, 0xf, 0xf);
+    AZD_DPP_STEP(u32_max, 0u, v, 0x112, 0xf, 0xf);
+    AZD_DPP_STEP(u32_max, 0u, v, 0x114, 0xf, 0xe);
+    AZD_DPP_STEP(u32_max, 0u, v, 0x118, 0xf, 0xc);
+    AZD_DPP_STEP(u32_max, 0u, v, 0x142, 0xa, 0xf);
+    AZD_DPP_STEP(u32_max, 0u, v, 0x143, 0xc, 0xf);
+    return (uint32_t)__builtin_amdgcn_readlane((int)v, 63);
+}
+__device__ __forceinline__ uint32_t wave_or_u32(uint32_t v) {
+    AZD_DPP_STEP(u32_or, 0u, v, 0x111, 0xf, 0xf);
+    AZD_DPP_STEP(u32_or, 0u, v, 0x112, 0xf, 0xf);
+    AZD_DPP_STEP(u32_or, 0u, v, 0x114, 0xf, 0xe);
+    AZD_DPP_STEP(u32_or, 0u, v, 0x118, 0xf, 0xc);
+    AZD_DPP_STEP(u32_or, 0u, v, 0x142, 0xa, 0xf);
+    AZD_DPP_STEP(u32_or, 0u, v, 0x143, 0xc, 0xf);
+    return (uint32_t)__builtin_amdgcn_readlane((int)v, 63);
+}
+// 64-bit lexicographic min / max = two 32-bit reductions (high word, then low word among the ties)
+__device__ __forceinline__ uint64_t wave_min_u64(uint64_t v) {
+    const uint32_t hi = (uint32_t)(v >> 32), lo = (uint32_t)v;
+    const uint32_t mh = wave_min_u32(hi);
+    const uint32_t ml = wave_min_u32(hi == mh ? lo : 0xFFFFFFFFu);
+    return ((uint64_t)mh << 32) | ml;
+}
+__device__ __forceinline__ uint64_t wave_max_u64(uint64_t v) {
+    const uint32_t hi = (uint32_t)(v >> 32), lo = (uint32_t)v;
+    const uint32_t mh = wave_max_u32(hi);
+    const uint32_t ml = wave_max_u32(hi == mh ? lo : 0u);
+    return ((uint64_t)mh << 32) | ml;
 }
 __device__ __forceinline__ int first_lane(uint64_t mask) { return __ffsll((unsigned long long)mask) - 1; }
 __device__ __forceinline__ uint32_t uni(uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); }
@@ -188,9 +216,7 @@ __device__ __forceinline__ void do_act(WaveLds &s, uint64_t (&perm)[KW], uint32_
 }
 
 __device__ __forceinline__ uint64_t wave_or_u64(uint64_t v) {
-#pragma unroll
-    for (int off = 32; off >= 1; off >>= 1) v |= __shfl_xor(v, off, 64);
-    return v;
+    return ((uint64_t)wave_or_u32((uint32_t)(v >> 32)) << 32) | wave_or_u32((uint32_t)v);
 }
 
 // lambda_1 cost contract (DESIGN.md "lambda_1"; stands in for faer at ordered_edge.rs:72-82):
@@ -405,81 +431,134 @@ __device__ void cascade(const Arenas &a, Agent<KW> &ag, WaveLds &s, uint32_t dyn
     NodeRec t = ag.nodes[dst];
     const uint32_t n_t_target = t.n_t;
     const float c = t.c_star;
-    uint32_t x0 = old ? (node_active(t) ? 0u : 1u) : 1u;
-    int cur = 0;
-    uint32_t n_cur = 1;
-    if (LANE == 0) {
-        lds_fr_id(dyn)[0] = src;
-        lds_fr_x(dyn)[0] = x0;
-    }
-    WAVE_SYNC();
-    while (n_cur != 0) {
-        uint32_t n_nxt = 0;
-        const int nxt = cur ^ 1;
-        CTR_MAX(10, n_cur);
-        for (uint32_t i = 0; i < n_cur; ++i) {
-            uint32_t u = lds_fr_id(dyn)[cur * FRONTIER_CAP + i];
-            uint32_t x = lds_fr_x(dyn)[cur * FRONTIER_CAP + i];
-            NodeRec r = ag.nodes[u];
-            r.exhausted += x;
-            if (r.c_star > c) r.c_star = c;
-            else r.n_t += 1;
-            if (old) r.n_t = r.n_t > n_t_target ? r.n_t : n_t_target;
-            if (LANE == 0) {
-                ag.nodes[u].c_star = r.c_star;
-                ag.nodes[u].n_t = r.n_t;
-                ag.nodes[u].exhausted = r.exhausted;
-            }
-            CTR_ADD(7, 1);
-            uint32_t up_x = node_active(r) ? 0u : 1u;
-            uint32_t e = r.first_in;
-            while (e != NONE) {
-                ArcRec ar = ag.arcs[e];
-                uint32_t p = ar.src;
-                int found = -1;
-                for (uint32_t base = 0; base < n_nxt; base += 64) {
-                    uint32_t j = base + (uint32_t)LANE;
-                    bool hit = (j < n_nxt) && (lds_fr_id(dyn)[nxt * FRONTIER_CAP + j] == p);
-                    uint64_t m = __ballot(hit);
-                    if (m) {
-                        found = (int)base + first_lane(m);
-                        break;
-                    }
-                }
-                if (found >= 0) {
-                    if (LANE == 0) lds_fr_x(dyn)[nxt * FRONTIER_CAP + found] += up_x;
-                } else {
-                    if (n_nxt >= FRONTIER_CAP) {
-                        ag.flags |= FLAG_FRONTIER_CAP;
-                        return;
-                    }
-                    if (LANE == 0) {
-                        lds_fr_id(dyn)[nxt * FRONTIER_CAP + n_nxt] = p;
-                        lds_fr_x(dyn)[nxt * FRONTIER_CAP + n_nxt] = up_x;
-                    }
-                    n_nxt += 1;
-                }
-                WAVE_SYNC();
-                e = ar.next_in;
-            }
+    // apply one Info to node u; returns the x it sends up (0 / 1) and its record
+    auto visit = [&](uint32_t u, uint32_t x, NodeRec &r) -> uint32_t {
+        r = ag.nodes[u];
+        r.exhausted += x;
+        if (r.c_star > c) r.c_star = c;
+        else r.n_t += 1;
+        if (old) r.n_t = r.n_t > n_t_target ? r.n_t : n_t_target;
+        if (LANE == 0) {
+            ag.nodes[u].c_star = r.c_star;
+            ag.nodes[u].n_t = r.n_t;
+            ag.nodes[u].exhausted = r.exhausted;
         }
-        cur = nxt;
-        n_cur = n_nxt;
+        CTR_ADD(7, 1);
+        return node_active(r) ? 0u : 1u;
+    };
+    // ---- fast path: while the frontier is one node whose only in-arc is the one that created it
+    // (NodeRec.in_src), the sweep is a plain walk up the creating chain: one record load per level,
+    // no LDS frontier.
+    uint32_t u1 = src, x1 = old ? (node_active(t) ? 0u : 1u) : 1u;
+    for (;;) {
+        CTR_MAX(10, 1);
+        NodeRec r;
+        const uint32_t up_x = visit(u1, x1, r);
+        if (r.first_in == NONE) {
+            if (r.in_src == NONE) return; // root done
+            u1 = r.in_src;
+            x1 = up_x;
+            continue;
+        }
+        // several parents: seed the LDS frontier with them and fall through to the general sweep
+        uint32_t n0 = 0;
+        if (LANE == 0 && r.in_src != NONE) {
+            lds_fr_id(dyn)[0] = r.in_src;
+            lds_fr_x(dyn)[0] = up_x;
+        }
+        if (r.in_src != NONE) n0 = 1;
+        WAVE_SYNC();
+        for (uint32_t e = r.first_in; e != NONE;) {
+            ArcRec ar = ag.arcs[e];
+            // parents of one node are distinct (one arc per (parent, action)), so no merge here
+            if (n0 >= FRONTIER_CAP) {
+                ag.flags |= FLAG_FRONTIER_CAP;
+                return;
+            }
+            if (LANE == 0) {
+                lds_fr_id(dyn)[n0] = ar.src;
+                lds_fr_x(dyn)[n0] = up_x;
+            }
+            n0 += 1;
+            e = ar.next_in;
+        }
+        WAVE_SYNC();
+        // ---- general level-synchronous sweep with an LDS-staged frontier
+        int cur = 0;
+        uint32_t n_cur = n0;
+        while (n_cur != 0) {
+            uint32_t n_nxt = 0;
+            const int nxt = cur ^ 1;
+            CTR_MAX(10, n_cur);
+            for (uint32_t i = 0; i < n_cur; ++i) {
+                const uint32_t u = lds_fr_id(dyn)[cur * FRONTIER_CAP + i];
+                const uint32_t x = lds_fr_x(dyn)[cur * FRONTIER_CAP + i];
+                NodeRec ru;
+                const uint32_t ux = visit(u, x, ru);
+                uint32_t e = ru.first_in;
+                uint32_t p = ru.in_src;
+                bool from_list = false;
+                if (p == NONE) {
+                    if (e == NONE) continue; // the root
+                    ArcRec ar = ag.arcs[e];
+                    p = ar.src;
+                    e = ar.next_in;
+                    from_list = true;
+                }
+                (void)from_list;
+                for (;;) {
+                    int found = -1;
+                    for (uint32_t base = 0; base < n_nxt; base += 64) {
+                        uint32_t j = base + (uint32_t)LANE;
+                        bool hit = (j < n_nxt) && (lds_fr_id(dyn)[nxt * FRONTIER_CAP + j] == p);
+                        uint64_t m = __ballot(hit);
+                        if (m) {
+                            found = (int)base + first_lane(m);
+                            break;
+                        }
+                    }
+                    if (found >= 0) {
+                        if (LANE == 0) lds_fr_x(dyn)[nxt * FRONTIER_CAP + found] += ux;
+                    } else {
+                        if (n_nxt >= FRONTIER_CAP) {
+                            ag.flags |= FLAG_FRONTIER_CAP;
+                            return;
+                        }
+                        if (LANE == 0) {
+                            lds_fr_id(dyn)[nxt * FRONTIER_CAP + n_nxt] = p;
+                            lds_fr_x(dyn)[nxt * FRONTIER_CAP + n_nxt] = ux;
+                        }
+                        n_nxt += 1;
+                    }
+                    WAVE_SYNC();
+                    if (e == NONE) break;
+                    ArcRec ar = ag.arcs[e];
+                    p = ar.src;
+                    e = ar.next_in;
+                }
+            }
+            cur = nxt;
+            n_cur = n_nxt;
+        }
+        return;
     }
 }
 
 // graph_operations.rs:18-30 add_arc (+ petgraph head insertion into dst's in-list)
+// `creating`: the arc that creates dst -- its source is stored in the node (NodeRec.in_src); only
+// later arcs into an existing node (transpositions) are chained through first_in / next_in.
 template <int KW>
-__device__ __forceinline__ uint32_t add_arc(Agent<KW> &ag, uint32_t src, uint32_t dst, uint32_t pp) {
+__device__ __forceinline__ uint32_t add_arc(Agent<KW> &ag, uint32_t src, uint32_t dst, uint32_t pp, bool creating) {
     uint32_t e = ag.n_arcs;
     if (LANE == 0) {
         ArcRec ar;
         ar.src = src;
         ar.dst = dst;
         ar.pp = pp;
-        ar.next_in = ag.nodes[dst].first_in;
+        ar.next_in = creating ? NONE : ag.nodes[dst].first_in;
         ag.arcs[e] = ar;
-        ag.nodes[dst].first_in = e;
+        if (creating) ag.nodes[dst].in_src = src;
+        else ag.nodes[dst].first_in = e;
         ag.preds[pp].arc = e;
         ag.preds[pp].child = dst;
     }
@@ -527,7 +606,7 @@ __global__ __launch_bounds__(64) void k_init_roots(Arenas a, const uint8_t *__re
     for (int w = 0; w < KW; ++w) zero[w] = 0;
     if (LANE == 0) {
         NodeRec r;
-        r.c = c; r.c_star = c; r.n_t = 0; r.exhausted = 0; r.act_begin = 0; r.act_end = 0; r.first_in = NONE; r.pad = 0;
+        r.c = c; r.c_star = c; r.n_t = 0; r.exhausted = 0; r.act_begin = 0; r.act_end = 0; r.first_in = NONE; r.in_src = NONE;
         a.nodes[(size_t)t * a.node_cap] = r;
 #pragma unroll
         for (int w = 0; w < KW; ++w) a.keys[((size_t)t * a.node_cap) * KW + w] = 0;
@@ -645,6 +724,10 @@ __device__ bool rollout_agent(const Arenas &a, const TolTable &tol, WaveLds &s, 
     WAVE_SYNC();
 
     bool expanded_new = false;
+    // The record of the node stepped into comes out of the parent's child gather (nothing modifies the
+    // tree between that gather and the step), which removes one of the three dependent loads per level.
+    NodeRec rec_next;
+    bool have_rec = false;
     const unsigned long long ph_begin = PH_NOW();
     for (uint32_t guard = 0;; ++guard) {
         if (guard > (1u << 22)) {
@@ -653,7 +736,10 @@ __device__ bool rollout_agent(const Arenas &a, const TolTable &tol, WaveLds &s, 
         }
         // ---- next_action (next_action.rs:11-26)
         const unsigned long long ph_sel0 = PH_NOW();
-        const NodeRec rec = ag.nodes[pos];
+        NodeRec rec;
+        if (have_rec) rec = rec_next;
+        else rec = ag.nodes[pos];
+        have_rec = false;
         const int depth = mask_count<KW>(path);
         const uint32_t tl = depth < tol.n_tol ? tol.tol[depth] : tol.tol_default;
         int kind = 0; // 0 None, 1 Visited, 2 Unvisited
@@ -665,6 +751,7 @@ __device__ bool rollout_agent(const Arenas &a, const TolTable &tol, WaveLds &s, 
             PredRec p[PRED_CHUNKS];
             bool valid[PRED_CHUNKS], expd[PRED_CHUNKS];
             float k_cstar[PRED_CHUNKS];
+            NodeRec crs[PRED_CHUNKS];
             uint64_t rkey[PRED_CHUNKS];
             uint32_t n_exp = 0;
             uint64_t exp_mask[PRED_CHUNKS];
@@ -679,6 +766,7 @@ __device__ bool rollout_agent(const Arenas &a, const TolTable &tol, WaveLds &s, 
                 rkey[ch] = ~0ull;
                 if (expd[ch]) {
                     NodeRec cr = ag.nodes[p[ch].child];
+                    crs[ch] = cr;
                     k_cstar[ch] = cr.c_star;
                     if (node_active(cr)) rkey[ch] = ((uint64_t)cr.n_t << 32) | (uint64_t)ordf(cr.c_star);
                 }
@@ -758,14 +846,25 @@ __device__ bool rollout_agent(const Arenas &a, const TolTable &tol, WaveLds &s, 
             if (kind == 1) {
                 // locate the chosen arc's prediction
                 uint32_t a_id = 0, child = 0;
+                NodeRec mcr;
+                mcr.c = 0.f; mcr.c_star = 0.f; mcr.n_t = 0; mcr.exhausted = 0; mcr.act_begin = 0; mcr.act_end = 0; mcr.first_in = NONE; mcr.in_src = NONE;
                 bool mine = false;
 #pragma unroll
                 for (int ch = 0; ch < PRED_CHUNKS; ++ch)
-                    if (expd[ch] && p[ch].arc == r_arc) { mine = true; a_id = p[ch].a_id; child = p[ch].child; }
+                    if (expd[ch] && p[ch].arc == r_arc) { mine = true; a_id = p[ch].a_id; child = p[ch].child; mcr = crs[ch]; }
                 uint64_t mm = __ballot(mine);
                 int src_lane = first_lane(mm);
                 sel_aid = (uint32_t)__shfl((int)a_id, src_lane, 64);
                 sel_child = (uint32_t)__shfl((int)child, src_lane, 64);
+                rec_next.c = __shfl(mcr.c, src_lane, 64);
+                rec_next.c_star = __shfl(mcr.c_star, src_lane, 64);
+                rec_next.n_t = (uint32_t)__shfl((int)mcr.n_t, src_lane, 64);
+                rec_next.exhausted = (uint32_t)__shfl((int)mcr.exhausted, src_lane, 64);
+                rec_next.act_begin = (uint32_t)__shfl((int)mcr.act_begin, src_lane, 64);
+                rec_next.act_end = (uint32_t)__shfl((int)mcr.act_end, src_lane, 64);
+                rec_next.first_in = (uint32_t)__shfl((int)mcr.first_in, src_lane, 64);
+                rec_next.in_src = (uint32_t)__shfl((int)mcr.in_src, src_lane, 64);
+                have_rec = true;
             }
         }
         kind = (int)uni((uint32_t)kind);
@@ -803,7 +902,7 @@ __device__ bool rollout_agent(const Arenas &a, const TolTable &tol, WaveLds &s, 
         CTR_ADD(18, PH_NOW() - ph_lk0);
         bool reset_to_root = false;
         if (hit != NONE) { // transposition (tree/mod.rs:172-179)
-            add_arc<KW>(ag, pos, hit, sel_pp);
+            add_arc<KW>(ag, pos, hit, sel_pp, false);
             WAVE_SYNC();
             const unsigned long long ph_c0 = PH_NOW();
             cascade<KW>(a, ag, s, dyn, pos, hit, true);
@@ -834,7 +933,7 @@ __device__ bool rollout_agent(const Arenas &a, const TolTable &tol, WaveLds &s, 
             const uint32_t v = ag.n_nodes;
             if (LANE == 0) {
                 NodeRec r;
-                r.c = c_as; r.c_star = c_as; r.n_t = 0; r.exhausted = 0; r.act_begin = 0; r.act_end = 0; r.first_in = NONE; r.pad = 0;
+                r.c = c_as; r.c_star = c_as; r.n_t = 0; r.exhausted = 0; r.act_begin = 0; r.act_end = 0; r.first_in = NONE; r.in_src = NONE;
                 ag.nodes[v] = r;
 #pragma unroll
                 for (int w = 0; w < KW; ++w) ag.keys[(size_t)v * KW + w] = path[w];
@@ -846,7 +945,7 @@ __device__ bool rollout_agent(const Arenas &a, const TolTable &tol, WaveLds &s, 
                 ag.cand_node = v;
             }
             WAVE_SYNC();
-            add_arc<KW>(ag, pos, v, sel_pp);
+            add_arc<KW>(ag, pos, v, sel_pp, true);
             WAVE_SYNC();
             uint64_t cur[KW], legal[KW];
             current_edges<KW>(s, A, cur);
@@ -1153,7 +1252,7 @@ void launch_observe(const Arenas &a, uint32_t n_obs_tol, void *stream) {
     DISPATCH_KW(a, l_observe, a, n_obs_tol, (hipStream_t)stream);
 }
 template <int KW, bool BIG>
-static void l_persist(const Arenas &a, const TolTable &tol, const FusedEval &ev, int n_calls, unsigned long long *log_key,
+static void l_persist(const Arenas &a, const PersistArgs *d_args, int n_calls, unsigned long long *log_key,
                       uint32_t *log_node, uint32_t dyn_stride, size_t dyn_bytes, hipStream_t st) {
     static bool attr_set = false;
     if (!attr_set) {
@@ -1161,7 +1260,7 @@ static void l_persist(const Arenas &a, const TolTable &tol, const FusedEval &ev,
         attr_set = true;
     }
     const int n_wg = (a.B + PERSIST_WAVES - 1) / PERSIST_WAVES;
-    k_persist<KW><<<dim3(n_wg), dim3(PERSIST_WAVES * 64), dyn_bytes, st>>>(a, tol, ev, n_calls, log_key, log_node, dyn_stride);
+    k_persist<KW><<<dim3(n_wg), dim3(PERSIST_WAVES * 64), dyn_bytes, st>>>(d_args, n_calls, log_key, log_node, dyn_stride);
     k_argmin_log<KW, BIG><<<dim3(1), dim3(64), dyn_lds_bytes(a.n), st>>>(a, n_calls, n_wg, log_key, log_node);
 }
 // LDS plan of the persistent step; returns false when the workgroup does not fit a CU
@@ -1178,9 +1277,9 @@ bool persist_plan(const Arenas &a, const FusedEval &ev, uint32_t *dyn_stride, si
     *dyn_bytes = total;
     return true;
 }
-void launch_persist(const Arenas &a, const TolTable &tol, const FusedEval &ev, int n_calls, unsigned long long *log_key,
+void launch_persist(const Arenas &a, const PersistArgs *d_args, int n_calls, unsigned long long *log_key,
                     uint32_t *log_node, uint32_t dyn_stride, size_t dyn_bytes, void *stream) {
-    DISPATCH_KW(a, l_persist, a, tol, ev, n_calls, log_key, log_node, dyn_stride, dyn_bytes, (hipStream_t)stream);
+    DISPATCH_KW(a, l_persist, a, d_args, n_calls, log_key, log_node, dyn_stride, dyn_bytes, (hipStream_t)stream);
 }
 template <int KW, bool BIG>
 static void l_modify_roots(const Arenas &a, uint64_t seed, uint64_t epoch, uint64_t first_agent, int kmin, int kmax,
