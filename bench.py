@@ -2,7 +2,8 @@
 """bench.py -- node-expansions/s of the c21 self-play hot path on N MI355X (one process per GPU).
 
 A "step" is one NablaOptimizer::par_roll_out_episodes call over the whole agent population
-(select / expand / backup kernels + the batched MLP forward + add_actions + argmin).  Every
+(select / expand / backup + the MLP forward + add_actions + argmin), executed by the CU-resident
+persistent kernel k_persist (16 agents per workgroup, evaluator on the matrix cores in-kernel).  Every
 EPOCH_CALLS steps the epoch boundary of the reference driver (04-c21-tree.rs:163-207:
 par_update_model, modify_root policy, par_reset_trees) runs INSIDE the timed region.
 
@@ -54,6 +55,8 @@ def algorithmic_bytes(c0, c1, state_dim):
     vec_bytes = 4 * state_dim * d["EXPANSIONS"]
     cascade_bytes = d["CASCADE_NODES"] * (32 + 12 + 16)
     total = sel_bytes + write_bytes + vec_bytes + cascade_bytes
+    # add_actions runs inside the persistent step too: prediction row read + new predictions written
+    total += 4 * (state_dim // 2) * d["EXPANSIONS"] + 16 * d["NEW_PREDS"]
     return total / exp, d
 
 
@@ -84,7 +87,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=1600)
     ap.add_argument("--warmup", type=int, default=100)
-    ap.add_argument("--cpu-steps", type=int, default=40)
+    ap.add_argument("--cpu-steps", type=int, default=200)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--chunk", type=int, default=100, help="calls per host round trip")
     args = ap.parse_args()
@@ -182,7 +185,7 @@ def main():
         tpath = os.path.join(ROOT, "profiles", "traffic.json")
         if os.path.exists(tpath):
             try:
-                traffic = json.load(open(tpath)).get("k_rollout_hbm_bytes_per_launch")
+                traffic = json.load(open(tpath)).get("k_persist_hbm_bytes_per_launch")
             except Exception:
                 traffic = None
         out = {
@@ -196,10 +199,12 @@ def main():
             "expansions": exp_total, "terminals": d["TERMINALS"], "transpositions": d["TRANSPOSITIONS"],
             "select_calls_per_expansion": d["SELECT_CALLS"] / max(1, d["EXPANSIONS"]),
             "epoch_losses": losses[-3:],
-            "phase_ms_per_step": {"rollout_kernel": avg_ms, "evaluator": timing["evaluator_ms"] / launches},
+            "calls_per_launch": args.steps / launches,
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "kernel": "k_rollout<3>",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "kernel": "k_persist<3>",
                          "algorithmic_bytes_per_expansion": bytes_per_exp, "avg_launch_ms": avg_ms,
+                         "mlp_flop_per_launch": 2.0 * sum(a * b for a, b in zip((space.STATE_DIM,) + HIDDEN, HIDDEN + (space.ACTION_DIM,)))
+                                                * ((B + 15) // 16 * 16) * args.steps / launches,
                          "note": "latency-bound pointer chasing: the rate target and the 40% roofline target are "
                                  "~3 orders of magnitude apart for this workload (SURVEY.md 8d)"},
         }
