@@ -127,6 +127,9 @@ struct azd_engine {
     bool initialised = false;
     // persistent (CU-resident) step
     bool persist_enabled = true;
+    bool barrier_step = false;
+    float *d_act_scratch = nullptr;
+    size_t act_scratch_floats = 0;
     azd::PersistArgs *d_pargs = nullptr;
     azd::PersistArgs *h_pargs = nullptr; // pinned
     unsigned long long *d_log_key = nullptr;
@@ -457,6 +460,7 @@ int azd_engine_create(azd_engine **out, const azd_engine_config *cfg, azd_evalua
     TRY(e->alloc(&a.argmin, 1));
     TRY(e->alloc(&a.status, 1));
     e->persist_enabled = (cfg->flags & AZD_ENGINE_NO_PERSISTENT_STEP) == 0;
+    e->barrier_step = (cfg->flags & AZD_ENGINE_ASYNC_STEP) == 0;
     e->log_calls = 1024;
     {
         const size_t n_wg = (B + 15) / 16;
@@ -506,6 +510,7 @@ int azd_engine_destroy(azd_engine *e) {
     if (e->h_status) (void)hipHostFree(e->h_status);
     if (e->h_argmin) (void)hipHostFree(e->h_argmin);
     if (e->h_pargs) (void)hipHostFree(e->h_pargs);
+    if (e->d_act_scratch) (void)hipFree(e->d_act_scratch);
     for (auto &it : e->ev_inflight) {
         (void)hipEventDestroy(it.second.first);
         (void)hipEventDestroy(it.second.second);
@@ -589,8 +594,22 @@ int azd_engine_par_roll_out_episodes(azd_engine *e, const uint32_t *tol, int n_t
     azd::FusedEval fe;
     uint32_t dyn_stride = 0;
     size_t dyn_bytes = 0;
-    if (e->persist_enabled && e->ev->fused_desc(&fe) && azd::persist_plan(e->a, fe, &dyn_stride, &dyn_bytes)) {
-        // CU-resident form: the whole call chain, n_calls times, in one launch per <= log_calls calls
+    const bool fusable = e->persist_enabled && e->ev->fused_desc(&fe);
+    const bool use_async = fusable && !e->barrier_step && azd::async_plan(e->a, fe, &dyn_stride, &dyn_bytes);
+    const bool use_barrier = fusable && !use_async && azd::persist_plan(e->a, fe, &dyn_stride, &dyn_bytes);
+    if (use_async || use_barrier) {
+        // CU-resident forms: the whole call chain, n_calls times, in one launch per <= log_calls calls
+        if (use_async && fe.kind == 3) {
+            const size_t need = (size_t)((e->a.B + 15) / 16) * 2 * 16 * (size_t)fe.max_hidden;
+            if (need > e->act_scratch_floats) {
+                AZD_HIP(hipStreamSynchronize(e->stream));
+                if (e->d_act_scratch) (void)hipFree(e->d_act_scratch);
+                e->d_act_scratch = nullptr;
+                e->act_scratch_floats = 0;
+                AZD_HIP(hipMalloc(&e->d_act_scratch, need * sizeof(float)));
+                e->act_scratch_floats = need;
+            }
+        }
         int left = n_calls;
         while (left > 0) {
             const int k = left < e->log_calls ? left : e->log_calls;
@@ -602,7 +621,8 @@ int azd_engine_par_roll_out_episodes(azd_engine *e, const uint32_t *tol, int n_t
             e->h_pargs->ev = fe;
             AZD_HIP(hipMemcpyAsync(e->d_pargs, e->h_pargs, sizeof(azd::PersistArgs), hipMemcpyHostToDevice, e->stream));
             e->time_begin(0);
-            azd::launch_persist(e->a, e->d_pargs, k, e->d_log_key, e->d_log_node, dyn_stride, dyn_bytes, e->stream);
+            if (use_async) azd::launch_async(e->a, e->d_pargs, k, e->d_log_key, e->d_act_scratch, fe.params, dyn_stride, dyn_bytes, e->stream);
+            else azd::launch_persist(e->a, e->d_pargs, k, e->d_log_key, e->d_log_node, dyn_stride, dyn_bytes, e->stream);
             e->time_end();
             e->ev->calls += (uint64_t)k;
             left -= k;
@@ -836,6 +856,7 @@ int azd_engine_counters(azd_engine *e, uint64_t *out) {
     for (int i = 0; i < a.B; ++i) {
         for (int k = 0; k < azd::NUM_COUNTERS; ++k) {
             unsigned long long v = h[(size_t)i * azd::NUM_COUNTERS + k];
+            if (k >= AZD_CTR_COUNT) continue;
             if (k == AZD_CTR_MAX_FRONTIER || k == AZD_CTR_MAX_DEPTH || k == AZD_CTR_TICKS_MAX_CALL) out[k] = std::max<uint64_t>(out[k], v);
             else out[k] += v;
         }

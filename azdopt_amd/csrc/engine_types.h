@@ -24,7 +24,7 @@ constexpr int PRED_CHUNKS = 2;               // a node holds at most 64*PRED_CHU
 constexpr int MAX_NODE_ACTIONS = 64 * PRED_CHUNKS;
 constexpr int FRONTIER_CAP = 256;            // LDS-staged cascade frontier per tree
 constexpr int MAX_TOL = 32;
-constexpr int NUM_COUNTERS = 24; // 0..15 public counters, 16..23 phase ticks (AZD_PHASE_PROFILE builds)
+constexpr int NUM_COUNTERS = 32; // 0..15 public counters, 16..24 phase ticks (AZD_PHASE_PROFILE builds), 25..27 evaluator service
 
 struct __attribute__((aligned(16))) NodeRec {
     float c;            // evaluate(cost(state))
@@ -144,6 +144,9 @@ void launch_add_actions(const Arenas &a, int root_mode, void *stream);
 void launch_rollout(const Arenas &a, const TolTable &tol, void *stream);
 void launch_argmin(const Arenas &a, int init_mode, void *stream);
 void launch_observe(const Arenas &a, uint32_t n_obs_tol, void *stream);
+bool async_plan(const Arenas &a, const FusedEval &ev, uint32_t *dyn_stride, size_t *dyn_bytes);
+void launch_async(const Arenas &a, const PersistArgs *d_args, int n_calls, unsigned long long *log_key, float *act_scratch,
+                  const float *params, uint32_t dyn_stride, size_t dyn_bytes, void *stream);
 bool persist_plan(const Arenas &a, const FusedEval &ev, uint32_t *dyn_stride, size_t *dyn_bytes);
 void launch_persist(const Arenas &a, const PersistArgs *d_args, int n_calls, unsigned long long *log_key,
                     uint32_t *log_node, uint32_t dyn_stride, size_t dyn_bytes, void *stream);

@@ -1163,6 +1163,7 @@ __global__ void k_hash_predictions(float *out, int batch, int action_dim, uint64
 }
 
 #include "persistent_step.inc"
+#include "async_step.inc"
 #include "root_policy.inc"
 
 // parity probe for the f32 primitives the selection rule depends on; four outputs per input pair:
@@ -1262,6 +1263,35 @@ static void l_persist(const Arenas &a, const PersistArgs *d_args, int n_calls, u
     const int n_wg = (a.B + PERSIST_WAVES - 1) / PERSIST_WAVES;
     k_persist<KW><<<dim3(n_wg), dim3(PERSIST_WAVES * 64), dyn_bytes, st>>>(d_args, n_calls, log_key, log_node, dyn_stride);
     k_argmin_log<KW, BIG><<<dim3(1), dim3(64), dyn_lds_bytes(a.n), st>>>(a, n_calls, n_wg, log_key, log_node);
+}
+template <int KW, bool BIG>
+static void l_async(const Arenas &a, const PersistArgs *d_args, int n_calls, unsigned long long *log_key, float *act_scratch,
+                    const float *params, uint32_t dyn_stride, size_t dyn_bytes, hipStream_t st) {
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute((const void *)k_async<KW>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 16 * 1024);
+        attr_set = true;
+    }
+    const int n_wg = (a.B + PERSIST_WAVES - 1) / PERSIST_WAVES;
+    (void)hipMemsetAsync(log_key, 0xFF, (size_t)n_calls * sizeof(unsigned long long), st);
+    k_async<KW><<<dim3(n_wg), dim3(PERSIST_WAVES * 64), dyn_bytes, st>>>(d_args, n_calls, log_key, act_scratch, dyn_stride, params, a.state_vecs, a.h_theta);
+    k_argmin_log1<KW, BIG><<<dim3(1), dim3(64), dyn_lds_bytes(a.n), st>>>(a, n_calls, log_key);
+}
+void launch_async(const Arenas &a, const PersistArgs *d_args, int n_calls, unsigned long long *log_key, float *act_scratch,
+                  const float *params, uint32_t dyn_stride, size_t dyn_bytes, void *stream) {
+    DISPATCH_KW(a, l_async, a, d_args, n_calls, log_key, act_scratch, params, dyn_stride, dyn_bytes, (hipStream_t)stream);
+}
+// LDS plan of the asynchronous step (no evaluator buffers in LDS)
+bool async_plan(const Arenas &a, const FusedEval &ev, uint32_t *dyn_stride, size_t *dyn_bytes) {
+    (void)ev;
+    if (a.B > 65536 || a.node_cap > 65536) return false; // (agent, node) are packed 16 + 16 bits in the argmin log
+    size_t stride = (dyn_lds_bytes(a.n) + 15) & ~(size_t)15;
+    size_t total = stride * PERSIST_WAVES;
+    const size_t static_lds = PERSIST_WAVES * (sizeof(WaveLds) + 16) + sizeof(AsyncCtl) + 256;
+    if (total + static_lds > 160 * 1024) return false;
+    *dyn_stride = (uint32_t)stride;
+    *dyn_bytes = total;
+    return true;
 }
 // LDS plan of the persistent step; returns false when the workgroup does not fit a CU
 bool persist_plan(const Arenas &a, const FusedEval &ev, uint32_t *dyn_stride, size_t *dyn_bytes) {

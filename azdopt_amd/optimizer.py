@@ -35,13 +35,14 @@ class NablaOptimizer:
     `init_states` and `modify_root` closures stay on the host and hand over packed roots."""
 
     def __init__(self, space, model, batch, device=0, first_agent=0, node_capacity=0, arc_capacity=0,
-                 prediction_capacity=0, path=ActionSet, persistent=True):
+                 prediction_capacity=0, path=ActionSet, persistent=True, async_step=False):
         if path is not ActionSet or not ActionSet.licensed_for(space):
             raise TypeError("only ActionSet paths on ActionsNeverRepeat + ActionOrderIndependent spaces are built")
         self.space, self.model, self.batch, self.first_agent = space, model, batch, first_agent
         self._L = _lib.lib()
         cfg = _lib.EngineConfig(space.SPACE_ID, space.n, batch, device, node_capacity, arc_capacity,
-                                prediction_capacity, first_agent, 0 if persistent else _lib.ENGINE_NO_PERSISTENT_STEP)
+                                prediction_capacity, first_agent,
+                                (0 if persistent else _lib.ENGINE_NO_PERSISTENT_STEP) | (_lib.ENGINE_ASYNC_STEP if async_step else 0))
         self._h = C.c_void_p()
         ev = model._h if model is not None else None
         _lib.check(self._L.azd_engine_create(C.byref(self._h), C.byref(cfg), ev), "azd_engine_create")

@@ -139,6 +139,10 @@ typedef struct azd_engine_config {
 /* run every phase of a call as its own kernel launch instead of the CU-resident persistent step
  * (the two forms produce identical trees; the persistent step is the fast one) */
 #define AZD_ENGINE_NO_PERSISTENT_STEP 1u
+/* CU-resident step with an asynchronous in-workgroup evaluator service (k_async: agents drift
+ * apart, waiting agents serve MFMA tile tasks) instead of the default workgroup barrier around the
+ * evaluator (k_persist).  Same results; measured on par at 4096 agents (profiles/README.md). */
+#define AZD_ENGINE_ASYNC_STEP 2u
 
 /* ArgminData<State, Cost> (az-discrete-opt/src/log.rs:1-11) for the c21 space */
 typedef struct azd_argmin {
@@ -177,7 +181,14 @@ enum { /* indices into azd_engine_counters' output */
     AZD_CTR_TICKS_MAX_CALL = 21, /* max over agents and calls of one agent's ticks in one call */
     AZD_CTR_TICKS_LAMBDA = 22,   /* inside NEWNODE: lambda_1 */
     AZD_CTR_TICKS_MATCHING = 23, /* inside NEWNODE: matching */
-    AZD_CTR_COUNT = 24
+    AZD_CTR_TICKS_WAIT = 24,     /* waiting for / serving the in-kernel evaluator */
+    /* evaluator service of the asynchronous step (always counted) */
+    AZD_CTR_EVAL_BATCHES = 25,
+    AZD_CTR_EVAL_ROWS = 26,
+    AZD_CTR_EVAL_TILES = 27,
+    AZD_CTR_TICKS_TILES = 28,   /* diagnostic build: ticks inside evaluator tile tasks */
+    AZD_CTR_TICKS_BATCH = 29,   /* diagnostic build: ticks from batch open to batch close, summed */
+    AZD_CTR_COUNT = 32
 };
 
 /* Allocates the device arenas.  `ev` may be NULL (external evaluator: drive the

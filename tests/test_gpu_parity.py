@@ -293,8 +293,8 @@ def test_mlp_update_matches_cpu_and_torch(az, orc):
         assert np.max(np.abs(pg - pt)) < 0.05 * cfg["lr"], it
 
 
-@pytest.mark.parametrize("persistent", [True, False])
-def test_topology_parity_with_mlp_predictions(az, orc, persistent):
+@pytest.mark.parametrize("persistent,async_step", [(True, False), (True, True), (False, False)])
+def test_topology_parity_with_mlp_predictions(az, orc, persistent, async_step):
     """End-to-end with the real MLP (in-kernel MFMA evaluator of the persistent step, or the
     launch-per-phase form): feed the GPU's own predictions to the oracle; trees must match
     bit-for-bit (MLP parity is tolerance-checked separately)."""
@@ -302,7 +302,7 @@ def test_topology_parity_with_mlp_predictions(az, orc, persistent):
     space = az.ROTModifyParentsOnce(n)
     model = az.ActionModel(B, space.STATE_DIM, space.ACTION_DIM, hidden=(256, 256, 256), seed=seed)
     parents, permitted = space.generate_roots(seed, B)
-    opt = az.NablaOptimizer.par_new(space, (parents, permitted), model, B, persistent=persistent)
+    opt = az.NablaOptimizer.par_new(space, (parents, permitted), model, B, persistent=persistent, async_step=async_step)
     oe = orc.Engine(n, B, threads=8)
     oe.new_begin(parents, permitted)
     oe.new_end(opt.predictions())
@@ -324,24 +324,37 @@ def test_persistent_step_equals_launch_per_phase(az, orc):
     n, B, seed = 19, 200, 6
     space = az.ROTModifyParentsOnce(n)
     roots = space.generate_roots(seed, B)
+    def same_engines(o1, i1, o2, i2):
+        assert i1 == i2
+        c1, c2 = o1.counters(), o2.counters()
+        for k in MAIN_CTRS:
+            assert c1[k] == c2[k], k
+        for i in range(B):
+            t1, t2 = o1.get_tree(i), o2.get_tree(i)
+            for f in t1.FIELDS:
+                a, b = getattr(t1, f), getattr(t2, f)
+                assert a.shape == b.shape and np.array_equal(a.view(np.uint32) if a.dtype.kind == "f" else a, b.view(np.uint32) if b.dtype.kind == "f" else b), (i, f)
+        a1, a2 = o1.argmin_data(), o2.argmin_data()
+        assert a1.eval == a2.eval and a1.agent == a2.agent and a1.node == a2.node
+
     opts = []
-    for persistent in (True, False):
+    for persistent, barrier in ((True, False), (True, True), (False, False)):
         model = az.HashStreamModel(space.STATE_DIM, space.ACTION_DIM, seed)
-        o = az.NablaOptimizer.par_new(space, roots, model, B, persistent=persistent)
+        o = az.NablaOptimizer.par_new(space, roots, model, B, persistent=persistent, async_step=async_step)
         imp = o.par_roll_out_episodes(TOL_REF, n_calls=150)
         opts.append((o, imp, model))
-    (o1, i1, _), (o2, i2, _) = opts
-    assert i1 == i2
-    c1, c2 = o1.counters(), o2.counters()
-    for k in MAIN_CTRS:
-        assert c1[k] == c2[k], k
-    for i in range(B):
-        t1, t2 = o1.get_tree(i), o2.get_tree(i)
-        for f in t1.FIELDS:
-            a, b = getattr(t1, f), getattr(t2, f)
-            assert a.shape == b.shape and np.array_equal(a.view(np.uint32) if a.dtype.kind == "f" else a, b.view(np.uint32) if b.dtype.kind == "f" else b), (i, f)
-    a1, a2 = o1.argmin_data(), o2.argmin_data()
-    assert a1.eval == a2.eval and a1.agent == a2.agent and a1.node == a2.node
+    same_engines(opts[0][0], opts[0][1], opts[1][0], opts[1][1])
+    same_engines(opts[0][0], opts[0][1], opts[2][0], opts[2][1])
+    # with the MLP, the asynchronous evaluator service and the barrier form run the same MFMA
+    # sequence per output element: identical trees after many calls in one launch
+    mopts = []
+    for async_step in (True, False):
+        model = az.ActionModel(B, space.STATE_DIM, space.ACTION_DIM, hidden=(256, 256, 256), seed=9)
+        o = az.NablaOptimizer.par_new(space, roots, model, B, async_step=async_step)
+        imp = o.par_roll_out_episodes(TOL_REF, n_calls=120)
+        mopts.append((o, imp, model))
+    same_engines(mopts[0][0], mopts[0][1], mopts[1][0], mopts[1][1])
+    assert mopts[0][0].counters()["EVAL_ROWS"] == mopts[0][0].counters()["EXPANSIONS"]
     # MLP rows: same states, both evaluator forms
     preds = []
     for persistent in (True, False):
