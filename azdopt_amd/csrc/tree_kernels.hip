@@ -267,9 +267,12 @@ __device__ __forceinline__ int matching_size_wave(const PackedTree &t, int n) {
     return m;
 }
 
-template <bool FULL>
-__device__ double lambda1_wave(const PackedTree &t, int n, uint32_t dyn) {
-    const uint64_t par0 = t.par0, par1 = t.par1;
+// NS > 0: the vertex count as a compile-time constant (the vertex loop unrolls: no loop branch,
+// constant LDS offsets and field shifts); NS = 0: runtime n.
+template <bool FULL, int NS>
+__device__ double lambda1_impl(const PackedTree &t, int n_rt, uint32_t dyn) {
+    const int n = NS ? NS : n_rt;
+    uint64_t par0 = t.par0, par1 = t.par1;
     const int nslot = n > 2 ? n - 2 : 1;
     const int l = LANE & 31;
     double *Pm = lds_pq(dyn) + l;
@@ -325,6 +328,13 @@ __device__ double lambda1_wave(const PackedTree &t, int n, uint32_t dyn) {
         hi = nhi;
     }
     return hi;
+}
+
+template <bool FULL>
+__device__ __forceinline__ double lambda1_wave(const PackedTree &t, int n, uint32_t dyn) {
+    // lambda1_impl<FULL, 19> (static unroll) is 1.8x faster in isolation (tools/probe_cost.py) but its
+    // register pressure spills the search loop around it: measured slower end to end, so not used.
+    return lambda1_impl<FULL, 0>(t, n, dyn);
 }
 
 // ordered_edge.rs:94-124 maximum_matching (leaf stripping), on bit masks.  Returns |matching|;
@@ -567,6 +577,7 @@ __device__ __forceinline__ uint32_t add_arc(Agent<KW> &ag, uint32_t src, uint32_
 }
 
 // ---------------------------------------------------------------- kernels
+#ifndef AZD_TU_ASYNC
 template <int KW, bool BIG>
 __global__ __launch_bounds__(64) void k_init_roots(Arenas a, const uint8_t *__restrict__ parents,
                                                    const uint64_t *__restrict__ permitted) {
@@ -624,6 +635,7 @@ __global__ __launch_bounds__(64) void k_init_roots(Arenas a, const uint8_t *__re
     write_state_vec<KW>(s, perm, A, a.state_vecs + (size_t)t * a.S);
 }
 
+#endif // !AZD_TU_ASYNC
 // graph_operations.rs:32-56 add_actions for the node the agent stands on.
 // root_mode = 1: par_new / par_reset_trees (every agent, node 0); 0: after a roll-out (agents
 // whose path is non-empty, optimizer/mod.rs:186).
@@ -681,6 +693,7 @@ __device__ void add_actions_agent(const Arenas &a, WaveLds &s, const int t, cons
     }
 }
 
+#ifndef AZD_TU_ASYNC
 template <int KW>
 __global__ __launch_bounds__(64) void k_add_actions(Arenas a, int root_mode) {
     __shared__ WaveLds s;
@@ -688,6 +701,7 @@ __global__ __launch_bounds__(64) void k_add_actions(Arenas a, int root_mode) {
     add_actions_agent<KW>(a, s, (int)blockIdx.x, root_mode);
 }
 
+#endif // !AZD_TU_ASYNC
 // tree/mod.rs:113-232 roll_out_episodes for every agent (optimizer/mod.rs:159-174)
 // One agent's call, run by one wavefront.  `s` is the wave's LDS block (action tables already
 // built), `dyn` the byte offset of its scratch region.  Returns true iff the call ended on a new
@@ -708,8 +722,7 @@ __device__ bool rollout_agent(const Arenas &a, const TolTable &tol, WaveLds &s, 
     ag.flags = 0;
     ag.cand_c = a.cand_c[t];
     ag.cand_node = a.cand_node[t];
-#pragma unroll
-    for (int k = LANE; k < NUM_COUNTERS; k += 64) s.ctr[k] = 0;
+    if (LANE < 24) s.ctr[LANE] = 0; // slots 24.. belong to the asynchronous step's evaluator service
 
     if (LANE < PARENTS_STRIDE) s.par[LANE] = a.cur_parents[(size_t)t * PARENTS_STRIDE + LANE];
     uint64_t perm[KW], path[KW];
@@ -1001,17 +1014,21 @@ __device__ bool rollout_agent(const Arenas &a, const TolTable &tol, WaveLds &s, 
             a.flags[t] = ag.flags;
             atomicAdd(&a.status->failed, 1ull);
         }
-        unsigned long long *ctr = a.counters + (size_t)t * NUM_COUNTERS;
-#pragma unroll
-        for (int k = 0; k < NUM_COUNTERS; ++k) {
-            if (k == 10 || k == 11 || k == 21) ctr[k] = s.ctr[k] > ctr[k] ? s.ctr[k] : ctr[k];
-            else if (s.ctr[k]) ctr[k] += s.ctr[k];
-        }
         if (expanded_new) atomicAdd(&a.status->expansions, 1ull);
+    }
+    // per-call counters -> the agent's global block, one counter per lane
+    if (LANE < 24) {
+        const int k = LANE;
+        const unsigned long long v = s.ctr[k];
+        unsigned long long *ctr = a.counters + (size_t)t * NUM_COUNTERS;
+        if (k == 10 || k == 11 || k == 21) {
+            if (v > ctr[k]) ctr[k] = v;
+        } else if (v) ctr[k] += v;
     }
     return expanded_new;
 }
 
+#ifndef AZD_TU_ASYNC
 template <int KW, bool BIG>
 __global__ __launch_bounds__(64) void k_rollout(Arenas a, TolTable tol) {
     __shared__ WaveLds s;
@@ -1020,6 +1037,7 @@ __global__ __launch_bounds__(64) void k_rollout(Arenas a, TolTable tol) {
 }
 
 
+#endif // !AZD_TU_ASYNC
 static_assert(PRED_CHUNKS == 2, "selection code addresses prediction chunks 0 and 1 explicitly");
 
 // optimizer/mod.rs:226-241: ArgminData.state = roots[tree] with the winner's ActionSet replayed
@@ -1065,6 +1083,7 @@ __device__ void argmin_replay(const Arenas &a, WaveLds &s, const uint32_t dyn, c
     }
 }
 
+#ifndef AZD_TU_ASYNC
 // optimizer/mod.rs:194-246 par_update_argmmim_data (init_mode = 0) and the argmin of par_new
 // (:92-101, init_mode = 1).  One block: a strided scan over agents for the lexicographic min of
 // (c, agent) among candidates with c < best (strict; cross-tree ties -> lowest agent, which the
@@ -1145,6 +1164,7 @@ __global__ __launch_bounds__(64) void k_observe(Arenas a, uint32_t n_obs_tol) {
     }
 }
 
+#endif // !AZD_TU_ASYNC
 // fixed prediction stream h(agent, call, a) = top 24 bits of key4(seed ^ "pred", agent, call, a) * 2^-24
 __device__ __forceinline__ uint64_t splitmix(uint64_t x) {
     x += 0x9E3779B97F4A7C15ull;
@@ -1152,6 +1172,7 @@ __device__ __forceinline__ uint64_t splitmix(uint64_t x) {
     x = (x ^ (x >> 27)) * 0x94D049BB133111EBull;
     return x ^ (x >> 31);
 }
+#ifndef AZD_TU_ASYNC
 __global__ void k_hash_predictions(float *out, int batch, int action_dim, uint64_t seed, uint64_t first_agent,
                                    uint64_t call) {
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -1162,8 +1183,52 @@ __global__ void k_hash_predictions(float *out, int batch, int action_dim, uint64
     out[i] = (float)(r >> 40) * (1.0f / 16777216.0f);
 }
 
+#endif // !AZD_TU_ASYNC
+// BIG is a spare specialisation flag (n > 19); the kernels no longer depend on it
+#define DISPATCH_KW(A, FN, ...)                                   \
+    switch ((A).KW) {                                             \
+    case 1: FN<1, false>(__VA_ARGS__); break;                     \
+    case 2: FN<2, false>(__VA_ARGS__); break;                     \
+    case 3:                                                       \
+        if ((A).n > 19) FN<3, true>(__VA_ARGS__);                 \
+        else FN<3, false>(__VA_ARGS__);                           \
+        break;                                                    \
+    default: FN<4, true>(__VA_ARGS__); break;                     \
+    }
+
 #include "persistent_step.inc"
+#ifdef AZD_TU_ASYNC
 #include "async_step.inc"
+template <int KW, bool BIG>
+static void l_async(const Arenas &a, const PersistArgs *d_args, int n_calls, unsigned long long *log_key, float *act_scratch,
+                    const float *params, uint32_t dyn_stride, size_t dyn_bytes, hipStream_t st) {
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute((const void *)k_async<KW>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 16 * 1024);
+        attr_set = true;
+    }
+    const int n_wg = (a.B + PERSIST_WAVES - 1) / PERSIST_WAVES;
+    (void)hipMemsetAsync(log_key, 0xFF, (size_t)n_calls * sizeof(unsigned long long), st);
+    k_async<KW><<<dim3(n_wg), dim3(PERSIST_WAVES * 64), dyn_bytes, st>>>(d_args, n_calls, log_key, act_scratch, dyn_stride, params, a.state_vecs, a.h_theta);
+    k_argmin_log1<KW, BIG><<<dim3(1), dim3(64), dyn_lds_bytes(a.n), st>>>(a, n_calls, log_key);
+}
+void launch_async(const Arenas &a, const PersistArgs *d_args, int n_calls, unsigned long long *log_key, float *act_scratch,
+                  const float *params, uint32_t dyn_stride, size_t dyn_bytes, void *stream) {
+    DISPATCH_KW(a, l_async, a, d_args, n_calls, log_key, act_scratch, params, dyn_stride, dyn_bytes, (hipStream_t)stream);
+}
+// LDS plan of the asynchronous step (no evaluator buffers in LDS)
+bool async_plan(const Arenas &a, const FusedEval &ev, uint32_t *dyn_stride, size_t *dyn_bytes) {
+    (void)ev;
+    if (a.B > 65536 || a.node_cap > 65536) return false; // (agent, node) are packed 16 + 16 bits in the argmin log
+    size_t stride = (dyn_lds_bytes(a.n) + 15) & ~(size_t)15;
+    size_t total = stride * PERSIST_WAVES;
+    const size_t static_lds = PERSIST_WAVES * (sizeof(WaveLds) + 16) + sizeof(AsyncCtl) + 256;
+    if (total + static_lds > 160 * 1024) return false;
+    *dyn_stride = (uint32_t)stride;
+    *dyn_bytes = total;
+    return true;
+}
+#else
 #include "root_policy.inc"
 
 // parity probe for the f32 primitives the selection rule depends on; four outputs per input pair:
@@ -1204,18 +1269,6 @@ __global__ __launch_bounds__(64) void k_probe_cost(const uint8_t *__restrict__ p
 }
 
 // ---------------------------------------------------------------- launchers
-// BIG is a spare specialisation flag (n > 19); the kernels no longer depend on it
-#define DISPATCH_KW(A, FN, ...)                                   \
-    switch ((A).KW) {                                             \
-    case 1: FN<1, false>(__VA_ARGS__); break;                     \
-    case 2: FN<2, false>(__VA_ARGS__); break;                     \
-    case 3:                                                       \
-        if ((A).n > 19) FN<3, true>(__VA_ARGS__);                 \
-        else FN<3, false>(__VA_ARGS__);                           \
-        break;                                                    \
-    default: FN<4, true>(__VA_ARGS__); break;                     \
-    }
-
 template <int KW, bool BIG>
 static void l_init_roots(const Arenas &a, const uint8_t *p, const uint64_t *m, hipStream_t st) {
     k_init_roots<KW, BIG><<<dim3(a.B), dim3(64), dyn_lds_bytes(a.n), st>>>(a, p, m);
@@ -1264,35 +1317,6 @@ static void l_persist(const Arenas &a, const PersistArgs *d_args, int n_calls, u
     k_persist<KW><<<dim3(n_wg), dim3(PERSIST_WAVES * 64), dyn_bytes, st>>>(d_args, n_calls, log_key, log_node, dyn_stride);
     k_argmin_log<KW, BIG><<<dim3(1), dim3(64), dyn_lds_bytes(a.n), st>>>(a, n_calls, n_wg, log_key, log_node);
 }
-template <int KW, bool BIG>
-static void l_async(const Arenas &a, const PersistArgs *d_args, int n_calls, unsigned long long *log_key, float *act_scratch,
-                    const float *params, uint32_t dyn_stride, size_t dyn_bytes, hipStream_t st) {
-    static bool attr_set = false;
-    if (!attr_set) {
-        (void)hipFuncSetAttribute((const void *)k_async<KW>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 16 * 1024);
-        attr_set = true;
-    }
-    const int n_wg = (a.B + PERSIST_WAVES - 1) / PERSIST_WAVES;
-    (void)hipMemsetAsync(log_key, 0xFF, (size_t)n_calls * sizeof(unsigned long long), st);
-    k_async<KW><<<dim3(n_wg), dim3(PERSIST_WAVES * 64), dyn_bytes, st>>>(d_args, n_calls, log_key, act_scratch, dyn_stride, params, a.state_vecs, a.h_theta);
-    k_argmin_log1<KW, BIG><<<dim3(1), dim3(64), dyn_lds_bytes(a.n), st>>>(a, n_calls, log_key);
-}
-void launch_async(const Arenas &a, const PersistArgs *d_args, int n_calls, unsigned long long *log_key, float *act_scratch,
-                  const float *params, uint32_t dyn_stride, size_t dyn_bytes, void *stream) {
-    DISPATCH_KW(a, l_async, a, d_args, n_calls, log_key, act_scratch, params, dyn_stride, dyn_bytes, (hipStream_t)stream);
-}
-// LDS plan of the asynchronous step (no evaluator buffers in LDS)
-bool async_plan(const Arenas &a, const FusedEval &ev, uint32_t *dyn_stride, size_t *dyn_bytes) {
-    (void)ev;
-    if (a.B > 65536 || a.node_cap > 65536) return false; // (agent, node) are packed 16 + 16 bits in the argmin log
-    size_t stride = (dyn_lds_bytes(a.n) + 15) & ~(size_t)15;
-    size_t total = stride * PERSIST_WAVES;
-    const size_t static_lds = PERSIST_WAVES * (sizeof(WaveLds) + 16) + sizeof(AsyncCtl) + 256;
-    if (total + static_lds > 160 * 1024) return false;
-    *dyn_stride = (uint32_t)stride;
-    *dyn_bytes = total;
-    return true;
-}
 // LDS plan of the persistent step; returns false when the workgroup does not fit a CU
 bool persist_plan(const Arenas &a, const FusedEval &ev, uint32_t *dyn_stride, size_t *dyn_bytes) {
     size_t stride = (dyn_lds_bytes(a.n) + 15) & ~(size_t)15;
@@ -1335,5 +1359,7 @@ void launch_probe_cost(const uint8_t *d_parents, int n, int count, int reps, int
 void launch_probe_math(const float *d_in, float *d_out, int n, void *stream) {
     hipLaunchKernelGGL(k_probe_math, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, d_in, d_out, n);
 }
+
+#endif // AZD_TU_ASYNC
 
 } // namespace azd

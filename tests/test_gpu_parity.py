@@ -338,7 +338,7 @@ def test_persistent_step_equals_launch_per_phase(az, orc):
         assert a1.eval == a2.eval and a1.agent == a2.agent and a1.node == a2.node
 
     opts = []
-    for persistent, barrier in ((True, False), (True, True), (False, False)):
+    for persistent, async_step in ((True, False), (True, True), (False, False)):
         model = az.HashStreamModel(space.STATE_DIM, space.ACTION_DIM, seed)
         o = az.NablaOptimizer.par_new(space, roots, model, B, persistent=persistent, async_step=async_step)
         imp = o.par_roll_out_episodes(TOL_REF, n_calls=150)

@@ -18,7 +18,8 @@ kind = sys.argv[3] if len(sys.argv) > 3 else "mlp"
 space = az.ROTModifyParentsOnce(19)
 model = (az.ActionModel(B, space.STATE_DIM, space.ACTION_DIM, hidden=(256, 256, 256), seed=0) if kind == "mlp"
          else az.HashStreamModel(space.STATE_DIM, space.ACTION_DIM, 0))
-opt = az.NablaOptimizer.par_new(space, space.generate_roots(0, B), model, B)
+async_step = len(sys.argv) > 4 and sys.argv[4] == "async"
+opt = az.NablaOptimizer.par_new(space, space.generate_roots(0, B), model, B, async_step=async_step)
 tol = ([200, 50, 50], 25)
 opt.par_roll_out_episodes(tol, n_calls=50)
 c0 = opt.counters()
