@@ -89,7 +89,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=100)
     ap.add_argument("--cpu-steps", type=int, default=200)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--chunk", type=int, default=100, help="calls per host round trip")
+    ap.add_argument("--chunk", type=int, default=800, help="calls per host round trip (<= one epoch)")
+    ap.add_argument("--async-step", action="store_true", help="asynchronous evaluator-service step (k_async) instead of the barrier step")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -114,7 +115,8 @@ def main():
     B_total = plan.total_agents
     model = az.ActionModel(B_total, space.STATE_DIM, space.ACTION_DIM, hidden=HIDDEN, seed=SEED, device=local_rank)
     roots = space.generate_roots(SEED, B, first_agent=plan.first_agent)
-    opt = az.NablaOptimizer.par_new(space, roots, model, B, device=local_rank, first_agent=plan.first_agent)
+    opt = az.NablaOptimizer.par_new(space, roots, model, B, device=local_rank, first_agent=plan.first_agent,
+                                    async_step=args.async_step)
 
     def barrier():
         if world > 1:
@@ -201,7 +203,7 @@ def main():
             "epoch_losses": losses[-3:],
             "calls_per_launch": args.steps / launches,
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "kernel": "k_persist<3>",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "kernel": "k_async<3>" if args.async_step else "k_persist<3>",
                          "algorithmic_bytes_per_expansion": bytes_per_exp, "avg_launch_ms": avg_ms,
                          "mlp_flop_per_launch": 2.0 * sum(a * b for a, b in zip((space.STATE_DIM,) + HIDDEN, HIDDEN + (space.ACTION_DIM,)))
                                                 * ((B + 15) // 16 * 16) * args.steps / launches,
