@@ -202,13 +202,21 @@ __global__ void k_loss_delta(const float *__restrict__ pred, const float *__rest
     }
     if (threadIdx.x == 0) partial[blockIdx.x] = s[0];
 }
-// db[j] = sum_i dZ[i][j]
-__global__ void k_col_sum(const float *__restrict__ dz, int M, int N, float *__restrict__ out) {
-    int j = blockIdx.x * blockDim.x + threadIdx.x;
-    if (j >= N) return;
+// db[j] = sum_i dZ[i][j]: 64 columns x 16 row-strides per block, fixed-order LDS tree over the strides
+__global__ __launch_bounds__(1024) void k_col_sum(const float *__restrict__ dz, int M, int N, float *__restrict__ out) {
+    __shared__ float s[16][65];
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+    const int j = blockIdx.x * 64 + tx;
     float acc = 0.f;
-    for (int i = 0; i < M; ++i) acc += dz[(size_t)i * N + j];
-    out[j] = acc;
+    if (j < N)
+        for (int i = ty; i < M; i += 16) acc += dz[(size_t)i * N + j];
+    s[ty][tx] = acc;
+    __syncthreads();
+    for (int off = 8; off > 0; off >>= 1) {
+        if (ty < off) s[ty][tx] += s[ty + off][tx];
+        __syncthreads();
+    }
+    if (ty == 0 && j < N) out[j] = s[0][tx];
 }
 // dfdx Adam with WeightDecay::L2: g += wd p; m, v; bias-corrected; p -= lr m^ / (sqrt(v^) + eps)
 __global__ void k_adam(float *__restrict__ p, const float *__restrict__ g, float *__restrict__ m, float *__restrict__ v,
@@ -320,7 +328,7 @@ struct MlpEvaluator : azd_evaluator {
             const float *x = (l == 0) ? d_s : d_act[(size_t)l];
             // dW[out][in] = dZ^T[out][batch] . X[batch][in]
             gemm<false, false>(st, dz, out, x, in, d_grads + w_off[(size_t)l], in, out, in, batch, EPI_NONE, 0, nullptr, nullptr, 0);
-            k_col_sum<<<(out + 255) / 256, 256, 0, st>>>(dz, batch, out, d_grads + b_off[(size_t)l]);
+            k_col_sum<<<(out + 63) / 64, 1024, 0, st>>>(dz, batch, out, d_grads + b_off[(size_t)l]);
             if (l > 0) {
                 // dX[batch][in] = (dZ[batch][out] . W[out][in]) masked by ReLU'(x)
                 gemm<true, false>(st, dz, out, d_params + w_off[(size_t)l], in, dx, in, batch, in, out, EPI_RELU_MASK, 0, nullptr, x, in);
