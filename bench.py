@@ -101,10 +101,19 @@ def main():
             raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N")
     import torch
     import torch.distributed as dist
+    # rehearsal on a one-GPU box (never used by the driver): AZD_BENCH_REHEARSE=1 puts every rank on
+    # cuda:0 and swaps RCCL for gloo with CPU staging, to exercise the N > 1 host logic
+    rehearse = os.environ.get("AZD_BENCH_REHEARSE") == "1"
+    if rehearse:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        if rehearse:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+    coll_dev = "cpu" if rehearse else f"cuda:{local_rank}"
 
     import azdopt_amd as az
     from azdopt_amd.parallel import ShardPlan, allgather_training_triple, global_argmin
@@ -135,7 +144,10 @@ def main():
             ptrs = opt.observe_dev(N_OBS_TOL)
             views = [torch.as_tensor(_DevView(p, (B, d)), device=f"cuda:{local_rank}")
                      for p, d in zip(ptrs, (space.STATE_DIM, space.ACTION_DIM, space.ACTION_DIM))]
-            gathered = allgather_training_triple(dist, torch, views, world)
+            if rehearse:
+                gathered = [g.cuda() for g in allgather_training_triple(dist, torch, [v.cpu() for v in views], world)]
+            else:
+                gathered = allgather_training_triple(dist, torch, views, world)
             torch.cuda.synchronize()
             losses.append(model.update_model_dev(B_total, *[g.data_ptr() for g in gathered], stream=opt.stream()))
         opt.par_reset_trees_c21(SEED, epoch)  # modify_root policy + reset on the device
@@ -166,7 +178,7 @@ def main():
 
     exp_local = c1["EXPANSIONS"] - c0["EXPANSIONS"]
     if world > 1:
-        t = torch.tensor([dt, float(exp_local)], dtype=torch.float64, device=f"cuda:{local_rank}")
+        t = torch.tensor([dt, float(exp_local)], dtype=torch.float64, device=coll_dev)
         tmax = t.clone()
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dist.all_reduce(t, op=dist.ReduceOp.SUM)
@@ -175,7 +187,7 @@ def main():
         dt_max, exp_total = dt, float(exp_local)
     am = opt.argmin_data()
     best_eval, best_cost = global_argmin(dist if world > 1 else None, torch, float(am.eval),
-                                         am.cost["lambda_1"] + len(am.cost["matching"]), local_rank)
+                                         am.cost["lambda_1"] + len(am.cost["matching"]), local_rank, device=coll_dev)
 
     if rank == 0:
         bytes_per_exp, d = algorithmic_bytes(c0, c1, space.STATE_DIM)
@@ -187,7 +199,8 @@ def main():
         tpath = os.path.join(ROOT, "profiles", "traffic.json")
         if os.path.exists(tpath):
             try:
-                traffic = json.load(open(tpath)).get("k_persist_hbm_bytes_per_launch")
+                per_call = json.load(open(tpath)).get("k_persist_hbm_bytes_per_call")
+                traffic = per_call * args.steps / launches if per_call else None  # PMC bytes per call x calls per launch
             except Exception:
                 traffic = None
         out = {
