@@ -32,6 +32,8 @@
 namespace {
 
 constexpr int MAXN = 32;
+constexpr int MAXC = 4;   /* colours of the Ramsey space */
+constexpr int SPACE_C21 = 0, SPACE_RAMSEY = 1;
 constexpr uint32_t NONE = 0xFFFFFFFFu;
 
 /* ------------------------------------------------------------------ */
@@ -96,14 +98,21 @@ inline int key_words(int n) { return (action_dim(n) + 63) / 64; }
 /* ------------------------------------------------------------------ */
 /* c21 state: ROTWithActionPermissions<N> (modify_parent_once.rs:8-12) */
 /* ------------------------------------------------------------------ */
+/* The Ramsey state RamseyCountsNoRecolor<N, E, C, B> (ramsey_counts/no_recolor.rs:9-13 around
+ * ramsey_counts/mod.rs:12-17) lives in the same struct: `nbr` = graphs[c].neighborhoods[v],
+ * `counts` = counts[c][e] (row-major C x E), `total` = total_counts, `permitted` = permitted_edges. */
 struct State {
     uint8_t parents[MAXN];
     std::set<uint32_t> permitted; /* BTreeSet<usize> */
+    uint32_t nbr[MAXC][MAXN];
+    std::vector<int32_t> counts;
+    int32_t total[MAXC];
 };
 
-struct Cost { /* Conjecture2Dot1Cost, connected_bitset_graph/mod.rs:340-344 */
+struct Cost { /* Conjecture2Dot1Cost, connected_bitset_graph/mod.rs:340-344; TotalCounts<C>, ramsey_counts/mod.rs:192-193 */
     double lambda1 = 0.0;
     std::vector<std::pair<int, int>> matching;
+    int32_t totals[MAXC] = {0, 0, 0, 0};
 };
 
 /* dense symmetric eigen-solve, cyclic Jacobi, f64: stands in for
@@ -244,10 +253,101 @@ float c21_eval(int n, double lambda1, int matching_size) {
     return slope * x;
 }
 
-struct Space { /* ROTModifyParentsOnce<N, Conjecture2Dot1Cost>, space.rs:14-125 */
+/* ------------------------------------------------------------------ */
+/* Ramsey space primitives                                             */
+/* ------------------------------------------------------------------ */
+inline int popc(uint32_t x) { return __builtin_popcount(x); }
+/* simple_graph/bitset_graph/mod.rs:164-185 count_cliques_inside */
+int count_cliques_inside(const uint32_t *nbr, uint32_t common, int size) {
+    if (size == 0) return 1;
+    if (size == 1) return popc(common);
+    int sum = 0;
+    for (uint32_t rest = common; rest; rest &= rest - 1) {
+        int u = __builtin_ctz(rest);
+        uint32_t n_u = common & nbr[u] & ((1u << u) - 1u); /* range_to(u) */
+        if (1 + popc(n_u) >= size) sum += count_cliques_inside(nbr, n_u, size - 1);
+    }
+    return sum;
+}
+/* ColoredCompleteBitsetGraph::color, bitset_graph/mod.rs:45-56 */
+inline int edge_color(const State &s, int C, int u, int v) {
+    for (int c = 0; c < C; ++c)
+        if ((s.nbr[c][u] >> v) & 1u) return c;
+    return -1;
+}
+/* RamseyCounts::new, ramsey_counts/mod.rs:20-68 */
+void ramsey_counts_new(State &s, int n, int C, int E, const int *sizes) {
+    s.counts.assign((size_t)C * E, 0);
+    for (int c = 0; c < C; ++c) {
+        int total = 0, pos = 0;
+        for (int v = 0; v < n; ++v)
+            for (int u = 0; u < v; ++u, ++pos) {
+                uint32_t common = s.nbr[c][v] & s.nbr[c][u];
+                int cnt = count_cliques_inside(s.nbr[c], common, sizes[c] - 2);
+                if ((s.nbr[c][v] >> u) & 1u) total += cnt;
+                s.counts[(size_t)c * E + pos] = cnt;
+            }
+        s.total[c] = total / (sizes[c] * (sizes[c] - 1) / 2);
+    }
+}
+/* reassign_color_count_adjustment, ramsey_counts/mod.rs:101-164 */
+void ramsey_adjust(State &s, int E, bool subtract, int u, int v, int color, int size) {
+    if (size <= 2) return;
+    int32_t *counts = &s.counts[(size_t)color * E];
+    const uint32_t *nbr = s.nbr[color];
+    uint32_t n_u = nbr[u], n_v = nbr[v], n_uv = n_u & n_v;
+    for (uint32_t r = n_u; r; r &= r - 1) { /* edge {v, w}, w in n_u */
+        int w = __builtin_ctz(r);
+        int change = count_cliques_inside(nbr, n_uv & nbr[w], size - 3);
+        if (change != 0) counts[colex_position(std::max(v, w), std::min(v, w))] += subtract ? -change : change;
+    }
+    for (uint32_t r = n_v; r; r &= r - 1) { /* edge {u, w}, w in n_v */
+        int w = __builtin_ctz(r);
+        int change = count_cliques_inside(nbr, n_uv & nbr[w], size - 3);
+        if (change != 0) counts[colex_position(std::max(u, w), std::min(u, w))] += subtract ? -change : change;
+    }
+    if (size == 3) return;
+    for (uint32_t r = n_uv; r; r &= r - 1) { /* edge {w, x}, w < x both in n_uv (tuple_combinations) */
+        int w = __builtin_ctz(r);
+        for (uint32_t q = r & (r - 1); q; q &= q - 1) {
+            int x = __builtin_ctz(q);
+            int change = count_cliques_inside(nbr, n_uv & nbr[w] & nbr[x], size - 4);
+            if (change != 0) counts[colex_position(x, w)] += subtract ? -change : change;
+        }
+    }
+}
+/* reassign_color, ramsey_counts/mod.rs:78-99 */
+void ramsey_reassign_color(State &s, int C, int E, const int *sizes, int edge_pos, int new_color) {
+    int v, u;
+    from_colex_position(edge_pos, &v, &u);
+    int old_color = edge_color(s, C, u, v);
+    s.nbr[old_color][v] ^= 1u << u;
+    s.nbr[old_color][u] ^= 1u << v;
+    ramsey_adjust(s, E, true, u, v, old_color, sizes[old_color]);
+    ramsey_adjust(s, E, false, u, v, new_color, sizes[new_color]);
+    s.nbr[new_color][v] ^= 1u << u;
+    s.nbr[new_color][u] ^= 1u << v;
+    s.total[old_color] -= s.counts[(size_t)old_color * E + edge_pos];
+    s.total[new_color] += s.counts[(size_t)new_color * E + edge_pos];
+}
+
+/* One runtime-tagged space: kind 0 = ROTModifyParentsOnce<N, Conjecture2Dot1Cost>
+ * (rooted_tree/space.rs:14-125), kind 1 = RamseySpaceNoEdgeRecolor<B32, N, E, C>
+ * (ramsey_counts/space.rs:10-176). */
+struct Space {
     int n, A, S, KW;
-    /* space.rs:56-73 act */
+    int kind = SPACE_C21;
+    int C = 0, E = 0, root_bytes = 0;
+    int sizes[MAXC] = {0, 0, 0, 0};
+    float weights[MAXC] = {0, 0, 0, 0};
+    /* space.rs:56-73 act; ramsey_counts/space.rs:71-86 */
     void act(State &s, int index) const {
+        if (kind == SPACE_RAMSEY) {
+            int edge_pos = index % E, new_color = index / E; /* `action`, :48-54 */
+            ramsey_reassign_color(s, C, E, sizes, edge_pos, new_color);
+            s.permitted.erase((uint32_t)edge_pos);
+            return;
+        }
         int parent, child;
         action_from_index(index, &parent, &child);
         s.parents[child] = (uint8_t)parent; /* set_parent, ordered_edge.rs:46-50 */
@@ -258,8 +358,31 @@ struct Space { /* ROTModifyParentsOnce<N, Conjecture2Dot1Cost>, space.rs:14-125 
         out.clear();
         for (int child = 2; child < n - 1; ++child) out.push_back((uint32_t)action_index(s.parents[child], child));
     }
-    /* space.rs:75-89 action_data: permitted ids (ascending) that are not current edges */
-    void action_data(const State &s, std::vector<uint32_t> &out) const {
+    /* space.rs:75-89 action_data: permitted ids (ascending) that are not current edges.
+     * Ramsey (ramsey_counts/space.rs:88-120): edges ascending, then new colours ascending;
+     * a_id = e_pos + new_color * E; `r` receives the reward hint folded to the f32
+     * r_sa = old_count * w[old] - new_count * w[new] of g_theta_star_sa (:163-165). */
+    void action_data(const State &s, std::vector<uint32_t> &out, std::vector<float> *r = nullptr) const {
+        if (kind == SPACE_RAMSEY) {
+            out.clear();
+            if (r) r->clear();
+            int pos = 0;
+            for (int v = 0; v < n; ++v)
+                for (int u = 0; u < v; ++u, ++pos) {
+                    if (!s.permitted.count((uint32_t)pos)) continue;
+                    int old_color = edge_color(s, C, v, u);
+                    for (int nc = 0; nc < C; ++nc) {
+                        if (nc == old_color) continue;
+                        out.push_back((uint32_t)(pos + nc * E));
+                        if (r) {
+                            int old_count = s.counts[(size_t)old_color * E + pos], new_count = s.counts[(size_t)nc * E + pos];
+                            r->push_back((float)old_count * weights[old_color] - (float)new_count * weights[nc]);
+                        }
+                    }
+                }
+            return;
+        }
+        if (r) r->clear();
         std::vector<uint32_t> cur;
         current_edge_positions(s, cur);
         out.clear();
@@ -274,6 +397,16 @@ struct Space { /* ROTModifyParentsOnce<N, Conjecture2Dot1Cost>, space.rs:14-125 
     /* space.rs:91-101 */
     void write_vec(const State &s, float *v) const {
         for (int i = 0; i < S; ++i) v[i] = 0.f;
+        if (kind == SPACE_RAMSEY) { /* ramsey_counts/space.rs:122-153 */
+            for (int i = 0; i < C * E; ++i) v[i] = (float)s.counts[i];
+            for (int c = 0; c < C; ++c) {
+                int pos = 0;
+                for (int x = 0; x < n; ++x)
+                    for (int u = 0; u < x; ++u, ++pos) v[C * E + c * E + pos] = ((s.nbr[c][x] >> u) & 1u) ? 1.0f : 0.f;
+            }
+            for (uint32_t e : s.permitted) v[2 * C * E + e] = 1.f;
+            return;
+        }
         std::vector<uint32_t> cur;
         current_edge_positions(s, cur);
         for (uint32_t e : cur) v[e] = 1.f;
@@ -284,15 +417,32 @@ struct Space { /* ROTModifyParentsOnce<N, Conjecture2Dot1Cost>, space.rs:14-125 
      * full = true: the ArgminData cost reported to the user (full f64 bracket) */
     Cost cost(const State &s, bool full = false) const {
         Cost c;
+        if (kind == SPACE_RAMSEY) { /* ramsey_counts/space.rs:155-157 */
+            for (int i = 0; i < C; ++i) c.totals[i] = s.total[i];
+            return c;
+        }
         c.lambda1 = lambda1_sturm(s.parents, n, !full);
         maximum_matching(s.parents, n, c.matching);
         return c;
     }
-    float evaluate(const Cost &c) const { return c21_eval(n, c.lambda1, (int)c.matching.size()); }
-    /* 04-c21-tree.rs:103 */
-    static float g_theta_star_sa(float c_s, float h_theta_sa) { return c_s - h_theta_sa; }
-    /* 04-c21-tree.rs:104 */
-    static float h_sa(float /*c_s*/, float /*c_as*/, float c_as_star) { return c_as_star; }
+    float evaluate(const Cost &c) const {
+        if (kind == SPACE_RAMSEY) { /* ramsey_counts/space.rs:159-165: f32 sum in colour order from 0 */
+            float sum = 0.0f;
+            for (int i = 0; i < C; ++i) sum = sum + (float)c.totals[i] * weights[i];
+            return sum;
+        }
+        return c21_eval(n, c.lambda1, (int)c.matching.size());
+    }
+    /* 04-c21-tree.rs:103; ramsey_counts/space.rs:167-172 */
+    float g_theta_star_sa(float c_s, float r_sa, float h_theta_sa) const {
+        if (kind == SPACE_RAMSEY) return c_s * h_theta_sa + r_sa * (1.0f - h_theta_sa);
+        return c_s - h_theta_sa;
+    }
+    /* 04-c21-tree.rs:104; ramsey_counts/space.rs:174-177 */
+    float h_sa(float /*c_s*/, float c_as, float c_as_star) const {
+        if (kind == SPACE_RAMSEY) return 1.0f - c_as_star / c_as;
+        return c_as_star;
+    }
 };
 
 /* ------------------------------------------------------------------ */
@@ -367,11 +517,13 @@ struct Tree { /* tree/mod.rs:28-32 */
         float c = nodes[id].w.c;
         uint32_t start = (uint32_t)predictions.size();
         std::vector<uint32_t> acts;
-        space.action_data(state, acts);
-        for (uint32_t a_id : acts) {
+        std::vector<float> r;
+        space.action_data(state, acts, &r);
+        for (size_t k = 0; k < acts.size(); ++k) {
+            uint32_t a_id = acts[k];
             Prediction p;
             p.a_id = a_id;
-            p.g_theta_sa = Space::g_theta_star_sa(c, h_theta[a_id]);
+            p.g_theta_sa = space.g_theta_star_sa(c, r.empty() ? 0.f : r[k], h_theta[a_id]);
             predictions.push_back(p);
         }
         uint32_t end = (uint32_t)predictions.size();
@@ -552,12 +704,12 @@ struct Tree { /* tree/mod.rs:28-32 */
     }
 
     /* tree/mod.rs:242-264 */
-    void write_observations(float *observations, float *weights, uint32_t n_t_as_tol) const {
+    void write_observations(const Space &space, float *observations, float *weights, uint32_t n_t_as_tol) const {
         float c_s = nodes[0].w.c;
         for (uint32_t e = nodes[0].next[0]; e != NONE; e = edges[e].next[0]) {
             const StateWeight &cw = nodes[edges[e].node[1]].w;
             if (!cw.is_active() || cw.n_t >= n_t_as_tol) {
-                float h = Space::h_sa(c_s, cw.c, cw.c_t_star);
+                float h = space.h_sa(c_s, cw.c, cw.c_t_star);
                 uint32_t a = predictions[edges[e].prediction_pos].a_id;
                 observations[a] = h;
                 weights[a] = 1.0f;
@@ -591,15 +743,37 @@ struct orc_engine {
 
 namespace {
 
+/* Packed roots.  c21: parents[n] + permitted action ids (A bits).  Ramsey: colour of every edge in
+ * colex order, colors[E], + permitted edge positions (E bits); both masks are KW words per agent. */
 void unpack_state(const Space &sp, const uint8_t *parents, const uint64_t *permitted, State &s) {
     std::memset(s.parents, 0, sizeof(s.parents));
+    if (sp.kind == SPACE_RAMSEY) {
+        std::memset(s.nbr, 0, sizeof(s.nbr));
+        int pos = 0;
+        for (int v = 0; v < sp.n; ++v)
+            for (int u = 0; u < v; ++u, ++pos) {
+                int c = parents[pos];
+                s.nbr[c][v] |= 1u << u;
+                s.nbr[c][u] |= 1u << v;
+            }
+        ramsey_counts_new(s, sp.n, sp.C, sp.E, sp.sizes);
+        s.permitted.clear();
+        for (int e = 0; e < sp.E; ++e)
+            if ((permitted[e >> 6] >> (e & 63)) & 1ull) s.permitted.insert((uint32_t)e);
+        return;
+    }
     for (int i = 0; i < sp.n; ++i) s.parents[i] = parents[i];
     s.permitted.clear();
     for (int a = 0; a < sp.A; ++a)
         if ((permitted[a >> 6] >> (a & 63)) & 1ull) s.permitted.insert((uint32_t)a);
 }
 void pack_state(const Space &sp, const State &s, uint8_t *parents, uint64_t *permitted) {
-    for (int i = 0; i < sp.n; ++i) parents[i] = s.parents[i];
+    if (sp.kind == SPACE_RAMSEY) {
+        int pos = 0;
+        for (int v = 0; v < sp.n; ++v)
+            for (int u = 0; u < v; ++u, ++pos) parents[pos] = (uint8_t)edge_color(s, sp.C, v, u);
+    } else
+        for (int i = 0; i < sp.n; ++i) parents[i] = s.parents[i];
     for (int w = 0; w < sp.KW; ++w) permitted[w] = 0;
     for (uint32_t a : s.permitted) permitted[a >> 6] |= 1ull << (a & 63);
 }
@@ -706,9 +880,8 @@ static void gen_one_root(uint64_t seed, uint64_t domain, uint64_t agent, int n, 
         permitted[perm[j] >> 6] |= 1ull << (perm[j] & 63);
     }
 }
-static void gen_permitted(uint64_t seed, uint64_t domain, uint64_t agent, int n, int k, uint64_t *permitted,
-                          uint64_t draw_base) {
-    int A = action_dim(n), KW = key_words(n);
+static void gen_permitted_of(uint64_t seed, uint64_t domain, uint64_t agent, int A, int KW, int k, uint64_t *permitted,
+                             uint64_t draw_base) {
     std::vector<uint32_t> perm(A);
     for (int i = 0; i < A; ++i) perm[i] = (uint32_t)i;
     for (int w = 0; w < KW; ++w) permitted[w] = 0;
@@ -716,6 +889,25 @@ static void gen_permitted(uint64_t seed, uint64_t domain, uint64_t agent, int n,
         uint32_t r = (uint32_t)j + below(key4(seed, domain, agent, draw_base + 64 + (uint64_t)j), (uint32_t)(A - j));
         std::swap(perm[j], perm[r]);
         permitted[perm[j] >> 6] |= 1ull << (perm[j] & 63);
+    }
+}
+/* Ramsey root generator spec (stands in for ColoredCompleteBitsetGraph::generate with uniform
+ * colour weights, bitset_graph/mod.rs:21-38, + RamseyCountsNoRecolor::generate, no_recolor.rs:38-54):
+ *   colour[e] = below(stream(1024 + e), C) for every edge position e;
+ *   permitted edges = first k of the Fisher-Yates shuffle of 0..E-1 (draws 64 + j). */
+static void gen_ramsey_root(uint64_t seed, uint64_t domain, uint64_t agent, int E, int C, int KW, int k, uint8_t *colors,
+                            uint64_t *permitted) {
+    for (int e = 0; e < E; ++e) colors[e] = (uint8_t)below(key4(seed, domain, agent, 1024 + (uint64_t)e), (uint32_t)C);
+    gen_permitted_of(seed, domain, agent, E, KW, k, permitted, 0);
+}
+void orc_gen_ramsey_roots(uint64_t seed, uint64_t epoch, uint64_t first_agent, int count, int n, int n_colors, int kmin,
+                          int kmax, uint8_t *colors, uint64_t *permitted) {
+    int E = n * (n - 1) / 2, KW = (E * n_colors + 63) / 64;
+    uint64_t domain = DOMAIN_ROOT ^ (epoch << 32);
+    for (int i = 0; i < count; ++i) {
+        uint64_t agent = first_agent + (uint64_t)i;
+        int k = kmin + (int)below(key4(seed, domain, agent, 0), (uint32_t)(kmax - kmin + 1));
+        gen_ramsey_root(seed, domain, agent, E, n_colors, KW, k, colors + (size_t)i * E, permitted + (size_t)i * KW);
     }
 }
 void orc_gen_roots(uint64_t seed, uint64_t epoch, uint64_t first_agent, int count, int n, int kmin, int kmax,
@@ -738,6 +930,7 @@ void orc_hash_predictions(uint64_t seed, uint64_t first_agent, int count, int ac
         }
 }
 
+static void engine_init(orc_engine *e, int batch, int threads);
 orc_engine *orc_create(int n, int batch, int threads) {
     if (n < 4 || n > MAXN) return nullptr;
     orc_engine *e = new orc_engine();
@@ -745,6 +938,33 @@ orc_engine *orc_create(int n, int batch, int threads) {
     e->space.A = action_dim(n);
     e->space.S = state_dim(n);
     e->space.KW = key_words(n);
+    e->space.root_bytes = n;
+    engine_init(e, batch, threads);
+    return e;
+}
+/* NablaOptimizer<RamseySpaceNoEdgeRecolor<B32, N, E, C>, M, ActionSet> (01-r333.rs:35-46, 02-r44.rs:35-47) */
+orc_engine *orc_create_ramsey(int n, int n_colors, const int *sizes, const float *weights, int batch, int threads) {
+    if (n < 2 || n > MAXN || n_colors < 2 || n_colors > MAXC) return nullptr;
+    for (int c = 0; c < n_colors; ++c)
+        if (sizes[c] < 2) return nullptr;
+    orc_engine *e = new orc_engine();
+    Space &sp = e->space;
+    sp.kind = SPACE_RAMSEY;
+    sp.n = n;
+    sp.C = n_colors;
+    sp.E = n * (n - 1) / 2;
+    sp.A = sp.E * sp.C;                /* ramsey_counts/space.rs:42 */
+    sp.S = sp.E * (2 * sp.C + 1);      /* :40 */
+    sp.KW = (sp.A + 63) / 64;
+    sp.root_bytes = sp.E;
+    for (int c = 0; c < n_colors; ++c) {
+        sp.sizes[c] = sizes[c];
+        sp.weights[c] = weights[c];
+    }
+    engine_init(e, batch, threads);
+    return e;
+}
+static void engine_init(orc_engine *e, int batch, int threads) {
     e->B = batch;
     e->threads = threads < 1 ? 1 : threads;
     e->roots.resize(batch);
@@ -757,7 +977,6 @@ orc_engine *orc_create(int n, int batch, int threads) {
     e->num_inspected_nodes.assign(batch, 0);
     e->ctrs.resize(batch);
     e->failed.assign(batch, 0);
-    return e;
 }
 void orc_destroy(orc_engine *e) { delete e; }
 const float *orc_state_vecs(orc_engine *e) { return e->state_vecs.data(); }
@@ -767,7 +986,7 @@ void orc_new_begin(orc_engine *e, const uint8_t *parents, const uint64_t *permit
     const Space &sp = e->space;
 #pragma omp parallel for num_threads(e->threads) schedule(dynamic, 16)
     for (int i = 0; i < e->B; ++i) {
-        unpack_state(sp, parents + (size_t)i * sp.n, permitted + (size_t)i * sp.KW, e->roots[i]);
+        unpack_state(sp, parents + (size_t)i * sp.root_bytes, permitted + (size_t)i * sp.KW, e->roots[i]);
         e->states[i] = e->roots[i];
         e->costs[i] = sp.cost(e->roots[i]);
         e->paths[i].clear();
@@ -828,7 +1047,7 @@ void orc_observe(orc_engine *e, uint32_t n_obs_tol, float *obs, float *weights) 
         sp.write_vec(e->roots[i], &e->state_vecs[(size_t)i * sp.S]);
         float *o = obs + (size_t)i * sp.A, *w = weights + (size_t)i * sp.A;
         for (int a = 0; a < sp.A; ++a) { o[a] = 0.f; w[a] = 0.f; }
-        e->trees[i].write_observations(o, w, n_obs_tol);
+        e->trees[i].write_observations(sp, o, w, n_obs_tol);
     }
 }
 
@@ -838,7 +1057,7 @@ void orc_reset_begin(orc_engine *e, const uint8_t *parents, const uint64_t *perm
 #pragma omp parallel for num_threads(e->threads) schedule(dynamic, 16)
     for (int i = 0; i < e->B; ++i) {
         e->last_positions[i] = 0;
-        unpack_state(sp, parents + (size_t)i * sp.n, permitted + (size_t)i * sp.KW, e->roots[i]);
+        unpack_state(sp, parents + (size_t)i * sp.root_bytes, permitted + (size_t)i * sp.KW, e->roots[i]);
         e->states[i] = e->roots[i];
         e->costs[i] = sp.cost(e->roots[i]);
         sp.write_vec(e->states[i], &e->state_vecs[(size_t)i * sp.S]);
@@ -859,7 +1078,7 @@ void orc_reset_end(orc_engine *e, const float *h) {
     }
 }
 
-/* 04-c21-tree.rs:172-206 with the seeded generator:
+/* 04-c21-tree.rs:172-206 and 02-r44.rs:196-228 (the same policy over either space) with the seeded generator:
  *   stream(i) = key4(seed, DOMAIN_RESET ^ (epoch << 32), agent, i)
  *   draw 0: node choice; draw 1: new permitted count; draws 2.. / 64..: as the
  *   root generator (fresh tree) or the permitted shuffle. */
@@ -875,14 +1094,16 @@ void orc_c21_modify_roots(orc_engine *e, uint64_t seed, uint64_t epoch, uint64_t
         std::vector<std::pair<const Path *, const StateWeight *>> n;
         for (auto &kv : t.positions) n.push_back({&kv.first, &t.nodes[kv.second].w});
         float c_root = n[0].second->c, c_root_star = n[0].second->c_t_star;
-        uint8_t *po = parents_out + (size_t)i * sp.n;
+        uint8_t *po = parents_out + (size_t)i * sp.root_bytes;
+        std::vector<uint64_t> scratch(sp.KW);
         uint64_t *mo = permitted_out + (size_t)i * sp.KW;
         uint64_t r0 = key4(seed, domain, agent, 0), r1 = key4(seed, domain, agent, 1);
         if (c_root == c_root_star) {
             int num_permitted = (int)state.permitted.size();
             if (num_permitted == kmax) {
                 int k = kmin + (int)below(r1, (uint32_t)(kmax - kmin + 1));
-                gen_one_root(seed, domain, agent, sp.n, k, po, mo, 0);
+                if (sp.kind == SPACE_RAMSEY) gen_ramsey_root(seed, domain, agent, sp.E, sp.C, sp.KW, k, po, mo);
+                else gen_one_root(seed, domain, agent, sp.n, k, po, mo, 0);
                 continue;
             }
             std::vector<const Path *> keep;
@@ -891,8 +1112,8 @@ void orc_c21_modify_roots(orc_engine *e, uint64_t seed, uint64_t epoch, uint64_t
             const Path *p = keep[below(r0, (uint32_t)keep.size())];
             for (uint32_t a : *p) sp.act(state, (int)a);
             int k = num_permitted + (int)below(r1, (uint32_t)(kmax - num_permitted + 1));
-            for (int v = 0; v < sp.n; ++v) po[v] = state.parents[v];
-            gen_permitted(seed, domain, agent, sp.n, k, mo, 0);
+            pack_state(sp, state, po, scratch.data());
+            gen_permitted_of(seed, domain, agent, sp.kind == SPACE_RAMSEY ? sp.E : sp.A, sp.KW, k, mo, 0);
         } else {
             float c_threshold = (c_root + 3.0f * c_root_star) / 4.0f;
             std::vector<const Path *> keep;
@@ -901,8 +1122,8 @@ void orc_c21_modify_roots(orc_engine *e, uint64_t seed, uint64_t epoch, uint64_t
             const Path *p = keep[below(r0, (uint32_t)keep.size())];
             for (uint32_t a : *p) sp.act(state, (int)a);
             int k = kmin + (int)below(r1, (uint32_t)(kmax - kmin + 1));
-            for (int v = 0; v < sp.n; ++v) po[v] = state.parents[v];
-            gen_permitted(seed, domain, agent, sp.n, k, mo, 0);
+            pack_state(sp, state, po, scratch.data());
+            gen_permitted_of(seed, domain, agent, sp.kind == SPACE_RAMSEY ? sp.E : sp.A, sp.KW, k, mo, 0);
         }
     }
 }
@@ -925,6 +1146,51 @@ void orc_argmin(orc_engine *e, uint8_t *parents, uint64_t *permitted, double *la
     *lambda1 = e->argmin_cost.lambda1;
     *matching_size = (int)e->argmin_cost.matching.size();
     *eval = e->argmin_eval;
+}
+
+void orc_argmin_totals(orc_engine *e, int32_t *totals) {
+    for (int c = 0; c < MAXC; ++c) totals[c] = e->argmin_cost.totals[c];
+}
+void orc_agent_totals(orc_engine *e, int agent, int32_t *totals) {
+    for (int c = 0; c < MAXC; ++c) totals[c] = e->costs[agent].totals[c];
+}
+/* the agent's live per-edge counts [C][E] (test access to RamseyCounts::counts) */
+void orc_agent_counts(orc_engine *e, int agent, int32_t *counts) {
+    const State &s = e->states[agent];
+    for (size_t i = 0; i < s.counts.size(); ++i) counts[i] = s.counts[i];
+}
+int orc_engine_state_dim(orc_engine *e) { return e->space.S; }
+int orc_engine_action_dim(orc_engine *e) { return e->space.A; }
+int orc_engine_key_words(orc_engine *e) { return e->space.KW; }
+int orc_engine_root_bytes(orc_engine *e) { return e->space.root_bytes; }
+
+/* ---- Ramsey space functions, exposed for the golden-vector tests ---- */
+/* RamseyCounts::new (ramsey_counts/mod.rs:20-68) on colours given per colex edge position */
+void orc_ramsey_counts_new(int n, int n_colors, const int *sizes, const uint8_t *colors, int32_t *counts, int32_t *totals) {
+    Space sp;
+    sp.kind = SPACE_RAMSEY; sp.n = n; sp.C = n_colors; sp.E = n * (n - 1) / 2; sp.A = sp.E * sp.C; sp.KW = (sp.A + 63) / 64;
+    for (int c = 0; c < n_colors; ++c) sp.sizes[c] = sizes[c];
+    State s;
+    std::vector<uint64_t> none(sp.KW, 0);
+    unpack_state(sp, colors, none.data(), s);
+    for (size_t i = 0; i < s.counts.size(); ++i) counts[i] = s.counts[i];
+    for (int c = 0; c < n_colors; ++c) totals[c] = s.total[c];
+}
+/* reassign_color (ramsey_counts/mod.rs:78-99) applied in sequence to `n_actions` action ids; returns
+ * the incrementally maintained counts/totals and the final colours */
+void orc_ramsey_act_sequence(int n, int n_colors, const int *sizes, uint8_t *colors, const int *actions, int n_actions,
+                             int32_t *counts, int32_t *totals) {
+    Space sp;
+    sp.kind = SPACE_RAMSEY; sp.n = n; sp.C = n_colors; sp.E = n * (n - 1) / 2; sp.A = sp.E * sp.C; sp.KW = (sp.A + 63) / 64;
+    for (int c = 0; c < n_colors; ++c) sp.sizes[c] = sizes[c];
+    State s;
+    std::vector<uint64_t> all(sp.KW, ~0ull);
+    unpack_state(sp, colors, all.data(), s);
+    for (int i = 0; i < n_actions; ++i) sp.act(s, actions[i]);
+    for (size_t i = 0; i < s.counts.size(); ++i) counts[i] = s.counts[i];
+    for (int c = 0; c < n_colors; ++c) totals[c] = s.total[c];
+    std::vector<uint64_t> scratch(sp.KW);
+    pack_state(sp, s, colors, scratch.data());
 }
 
 void orc_tree_sizes(orc_engine *e, int agent, int *n_nodes, int *n_edges, int *n_preds) {

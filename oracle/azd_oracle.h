@@ -12,6 +12,8 @@
  *   az-discrete-opt/src/nabla/model/{mod,dfdx}.rs
  *   graph-state/src/rooted_tree/{mod,modify_parent_once,ordered_edge,space}.rs
  *   graph-state/src/simple_graph/edge.rs
+ *   graph-state/src/ramsey_counts/{mod,no_recolor,space}.rs,
+ *   graph-state/src/simple_graph/bitset_graph/mod.rs (Ramsey space; drivers 01-r333.rs, 02-r44.rs)
  *   graph-state/examples/04-c21-tree.rs (driver semantics)
  *
  * Pinning status (see DESIGN.md "Oracle"):
@@ -60,6 +62,25 @@ void orc_hash_predictions(uint64_t seed, uint64_t first_agent, int count, int ac
 
 /* ---- engine = NablaOptimizer<ROTModifyParentsOnce<N>, M, ActionSet> ---- */
 orc_engine *orc_create(int n, int batch, int threads);
+/* ---- engine = NablaOptimizer<RamseySpaceNoEdgeRecolor<B32, N, E, C>, M, ActionSet>
+ * (ramsey_counts/space.rs; drivers 01-r333.rs, 02-r44.rs).  Packed roots: `parents` carries the
+ * colour of every edge in colex order (E bytes per agent), `permitted` the permitted edge
+ * positions (E bits in KW = ceil(E*C/64) words per agent).  The c21-named calls below
+ * (orc_c21_modify_roots, orc_argmin's lambda1/matching) have Ramsey counterparts. ---- */
+orc_engine *orc_create_ramsey(int n, int n_colors, const int *sizes, const float *weights, int batch, int threads);
+void orc_gen_ramsey_roots(uint64_t seed, uint64_t epoch, uint64_t first_agent, int count, int n, int n_colors,
+                          int kmin, int kmax, uint8_t *colors, uint64_t *permitted);
+void orc_argmin_totals(orc_engine *e, int32_t *totals /* [4] */);
+void orc_agent_totals(orc_engine *e, int agent, int32_t *totals /* [4] */);
+void orc_agent_counts(orc_engine *e, int agent, int32_t *counts /* [C*E] */);
+int orc_engine_state_dim(orc_engine *e);
+int orc_engine_action_dim(orc_engine *e);
+int orc_engine_key_words(orc_engine *e);
+int orc_engine_root_bytes(orc_engine *e);
+void orc_ramsey_counts_new(int n, int n_colors, const int *sizes, const uint8_t *colors, int32_t *counts,
+                           int32_t *totals);                       /* ramsey_counts/mod.rs:20-68 */
+void orc_ramsey_act_sequence(int n, int n_colors, const int *sizes, uint8_t *colors, const int *actions,
+                             int n_actions, int32_t *counts, int32_t *totals); /* mod.rs:78-164 */
 void orc_destroy(orc_engine *e);
 /* par_new (optimizer/mod.rs:39-118) split around the model call at :72 */
 void orc_new_begin(orc_engine *e, const uint8_t *parents, const uint64_t *permitted);

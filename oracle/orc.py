@@ -71,6 +71,16 @@ def lib():
     sig("orc_tree_sizes", None, vp, C.c_int, i32p, i32p, i32p)
     sig("orc_export_tree", None, vp, C.c_int, *([vp] * 13))
     sig("orc_agent_state", None, vp, C.c_int, vp, vp, vp, u32p, f64p, i32p)
+    sig("orc_create_ramsey", vp, C.c_int, C.c_int, vp, vp, C.c_int, C.c_int)
+    sig("orc_gen_ramsey_roots", None, C.c_uint64, C.c_uint64, C.c_uint64, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
+        vp, vp)
+    sig("orc_argmin_totals", None, vp, vp)
+    sig("orc_agent_totals", None, vp, C.c_int, vp)
+    sig("orc_agent_counts", None, vp, C.c_int, vp)
+    for name in ("state_dim", "action_dim", "key_words", "root_bytes"):
+        sig("orc_engine_" + name, C.c_int, vp)
+    sig("orc_ramsey_counts_new", None, C.c_int, C.c_int, vp, vp, vp, vp)
+    sig("orc_ramsey_act_sequence", None, C.c_int, C.c_int, vp, vp, vp, C.c_int, vp, vp)
     sig("orc_mlp_create", vp, C.c_int, vp, C.c_int, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float,
         C.c_uint64, C.c_int)
     sig("orc_mlp_destroy", None, vp)
@@ -94,6 +104,38 @@ def gen_roots(seed, epoch, first_agent, count, n, kmin, kmax):
     permitted = np.zeros((count, kw), np.uint64)
     L.orc_gen_roots(seed, epoch, first_agent, count, n, kmin, kmax, _p(parents), _p(permitted))
     return parents, permitted
+
+
+def gen_ramsey_roots(seed, epoch, first_agent, count, n, n_colors, kmin, kmax):
+    e = n * (n - 1) // 2
+    kw = (e * n_colors + 63) // 64
+    colors = np.zeros((count, e), np.uint8)
+    permitted = np.zeros((count, kw), np.uint64)
+    lib().orc_gen_ramsey_roots(seed, epoch, first_agent, count, n, n_colors, kmin, kmax, _p(colors), _p(permitted))
+    return colors, permitted
+
+
+def ramsey_counts_new(n, sizes, colors):
+    """RamseyCounts::new: (counts [C][E], totals [C]) of the colouring given per colex edge position"""
+    sizes = np.ascontiguousarray(sizes, np.int32)
+    colors = np.ascontiguousarray(colors, np.uint8)
+    c, e = len(sizes), n * (n - 1) // 2
+    counts = np.zeros((c, e), np.int32)
+    totals = np.zeros(c, np.int32)
+    lib().orc_ramsey_counts_new(n, c, _p(sizes), _p(colors), _p(counts), _p(totals))
+    return counts, totals
+
+
+def ramsey_act_sequence(n, sizes, colors, actions):
+    """apply action ids in order with the incremental reassign_color; returns (colors, counts, totals)"""
+    sizes = np.ascontiguousarray(sizes, np.int32)
+    colors = np.array(colors, np.uint8)
+    actions = np.ascontiguousarray(actions, np.int32)
+    c, e = len(sizes), n * (n - 1) // 2
+    counts = np.zeros((c, e), np.int32)
+    totals = np.zeros(c, np.int32)
+    lib().orc_ramsey_act_sequence(n, c, _p(sizes), _p(colors), _p(actions), len(actions), _p(counts), _p(totals))
+    return colors, counts, totals
 
 
 def hash_predictions(seed, first_agent, count, action_dim, call):
@@ -128,12 +170,21 @@ class Tree:
 class Engine:
     """NablaOptimizer-shaped driver of the oracle with an injectable model."""
 
-    def __init__(self, n, batch, threads=1):
+    def __init__(self, n, batch, threads=1, ramsey=None):
+        """ramsey = (sizes, weights) selects RamseySpaceNoEdgeRecolor<B32, n, E, C>; default the c21 space"""
         self.L = lib()
         self.n, self.B = n, batch
-        self.S, self.A, self.KW = self.L.orc_state_dim(n), self.L.orc_action_dim(n), self.L.orc_key_words(n)
-        self.h = self.L.orc_create(n, batch, threads)
+        if ramsey is None:
+            self.h = self.L.orc_create(n, batch, threads)
+        else:
+            sizes = np.ascontiguousarray(ramsey[0], np.int32)
+            weights = np.ascontiguousarray(ramsey[1], np.float32)
+            self.C = len(sizes)
+            self.h = self.L.orc_create_ramsey(n, len(sizes), _p(sizes), _p(weights), batch, threads)
         assert self.h
+        self.S, self.A, self.KW = (self.L.orc_engine_state_dim(self.h), self.L.orc_engine_action_dim(self.h),
+                                   self.L.orc_engine_key_words(self.h))
+        self.RB = self.L.orc_engine_root_bytes(self.h)
 
     def __del__(self):
         if getattr(self, "h", None):
@@ -177,7 +228,7 @@ class Engine:
         self.L.orc_reset_end(self.h, _p(h))
 
     def modify_roots(self, seed, epoch, first_agent, kmin, kmax):
-        parents = np.zeros((self.B, self.n), np.uint8)
+        parents = np.zeros((self.B, self.RB), np.uint8)
         permitted = np.zeros((self.B, self.KW), np.uint64)
         self.L.orc_c21_modify_roots(self.h, seed, epoch, first_agent, kmin, kmax, _p(parents), _p(permitted))
         return parents, permitted
@@ -187,8 +238,23 @@ class Engine:
         self.L.orc_counters(self.h, _p(out))
         return {k: int(out[v]) for k, v in CTR.items()}
 
+    def argmin_totals(self):
+        t = np.zeros(4, np.int32)
+        self.L.orc_argmin_totals(self.h, _p(t))
+        return t
+
+    def agent_totals(self, agent):
+        t = np.zeros(4, np.int32)
+        self.L.orc_agent_totals(self.h, agent, _p(t))
+        return t
+
+    def agent_counts(self, agent):
+        c = np.zeros((self.C, self.RB), np.int32)
+        self.L.orc_agent_counts(self.h, agent, _p(c))
+        return c
+
     def argmin(self):
-        parents = np.zeros(self.n, np.uint8)
+        parents = np.zeros(self.RB, np.uint8)
         permitted = np.zeros(self.KW, np.uint64)
         lam, mu, ev = C.c_double(), C.c_int32(), C.c_float()
         self.L.orc_argmin(self.h, _p(parents), _p(permitted), C.byref(lam), C.byref(mu), C.byref(ev))
@@ -211,7 +277,7 @@ class Engine:
         return t
 
     def agent_state(self, agent):
-        parents = np.zeros(self.n, np.uint8)
+        parents = np.zeros(self.RB, np.uint8)
         permitted = np.zeros(self.KW, np.uint64)
         path = np.zeros(self.KW, np.uint64)
         pos, lam, mu = C.c_uint32(), C.c_double(), C.c_int32()
