@@ -5,9 +5,9 @@ NablaOptimizer (optimizer/mod.rs), NablaModel / ActionModel / TrivialModel (mode
 space ROTModifyParentsOnce and the ActionSet path with its symmetry axioms."""
 from ._lib import ACT_NONE, ACT_RELU, ACT_SIGMOID, AzdError, build, lib  # noqa: F401
 from .model import ActionModel, HashStreamModel, NablaModel, TrivialModel  # noqa: F401
-from .optimizer import ArgminData, NablaOptimizer, TreeView  # noqa: F401
+from .optimizer import ArgminData, NablaOptimizer, RamseyArgminData, TreeView  # noqa: F401
 from . import sinks  # noqa: F401
-from .space import ActionOrderIndependent, ActionSet, ActionsNeverRepeat, ROTModifyParentsOnce  # noqa: F401
+from .space import ActionOrderIndependent, ActionSet, ActionsNeverRepeat, RamseySpaceNoEdgeRecolor, ROTModifyParentsOnce  # noqa: F401
 
 
 def device_count():

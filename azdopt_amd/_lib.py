@@ -20,6 +20,7 @@ ACT_NONE, ACT_RELU, ACT_SIGMOID = 0, 1, 2
 ENGINE_NO_PERSISTENT_STEP = 1
 ENGINE_ASYNC_STEP = 2
 SPACE_C21 = 1
+SPACE_RAMSEY = 2
 
 
 class AzdError(RuntimeError):
@@ -38,7 +39,13 @@ class AdamConfig(C.Structure):  # dfdx AdamConfig as set at 04-c21-tree.rs:87-92
 class EngineConfig(C.Structure):
     _fields_ = [("space_id", C.c_int), ("n", C.c_int), ("batch", C.c_int), ("device", C.c_int),
                 ("node_capacity", C.c_int), ("arc_capacity", C.c_int), ("prediction_capacity", C.c_int),
-                ("first_agent", C.c_uint64), ("flags", C.c_uint32)]
+                ("first_agent", C.c_uint64), ("flags", C.c_uint32),
+                ("n_colors", C.c_int), ("clique_sizes", C.c_int * 4), ("color_weights", C.c_float * 4)]
+
+
+class RamseyArgmin(C.Structure):  # ArgminData<RamseyCountsNoRecolor, TotalCounts<C>>
+    _fields_ = [("colors", C.c_uint8 * 256), ("permitted", C.c_uint64 * 4), ("totals", C.c_int32 * 4),
+                ("eval", C.c_float), ("agent", C.c_int32), ("node", C.c_uint32)]
 
 
 class Argmin(C.Structure):  # ArgminData<State, Cost>, az-discrete-opt/src/log.rs:1-11
@@ -99,6 +106,13 @@ def lib():
     sig("azd_engine_par_update_model", C.c_int, vp, C.c_uint32, f32p)
     sig("azd_engine_par_reset_trees", C.c_int, vp, vp, vp)
     sig("azd_engine_argmin_data", C.c_int, vp, C.POINTER(Argmin))
+    sig("azd_engine_ramsey_argmin_data", C.c_int, vp, C.POINTER(RamseyArgmin))
+    sig("azd_engine_ramsey_agent_counts", C.c_int, vp, C.c_int, vp, vp)
+    sig("azd_ramsey_state_dim", C.c_int, C.c_int, C.c_int)
+    sig("azd_ramsey_action_dim", C.c_int, C.c_int, C.c_int)
+    sig("azd_ramsey_key_words", C.c_int, C.c_int, C.c_int)
+    sig("azd_ramsey_generate_roots", C.c_int, C.c_uint64, C.c_uint64, C.c_uint64, C.c_int, C.c_int, C.c_int, C.c_int,
+        C.c_int, vp, vp)
     sig("azd_c21_modify_roots", C.c_int, vp, C.c_uint64, C.c_uint64, C.c_int, C.c_int, vp, vp)
     sig("azd_c21_modify_roots_dev", C.c_int, vp, C.c_uint64, C.c_uint64, C.c_int, C.c_int, vp, vp)
     sig("azd_engine_par_reset_trees_c21", C.c_int, vp, C.c_uint64, C.c_uint64, C.c_int, C.c_int)

@@ -64,4 +64,42 @@ void c21_generate_roots(uint64_t seed, uint64_t epoch, uint64_t first_agent, int
     }
 }
 
+// ---- Ramsey space: seeded stand-in for the drivers' init_state closure (01-r333.rs:84-90,
+// 02-r44.rs:84-90: ColoredCompleteBitsetGraph::generate with uniform colour weights +
+// RamseyCountsNoRecolor::generate).  colour[e] = below(draw 1024 + e, C); permitted edges = first k of
+// the Fisher-Yates shuffle of 0..E-1 (draws 64 + j).
+int ramsey_edges(int n) { return n * (n - 1) / 2; }
+int ramsey_state_dim(int n, int c) { return ramsey_edges(n) * (2 * c + 1); }
+int ramsey_action_dim(int n, int c) { return ramsey_edges(n) * c; }
+int ramsey_key_words(int n, int c) { return (ramsey_action_dim(n, c) + 63) / 64; }
+
+void shuffle_mask(uint64_t seed, uint64_t domain, uint64_t agent, int universe, int words, int k, uint64_t *mask) {
+    std::vector<uint32_t> perm((size_t)universe);
+    for (int i = 0; i < universe; ++i) perm[(size_t)i] = (uint32_t)i;
+    for (int w = 0; w < words; ++w) mask[w] = 0;
+    for (int j = 0; j < k; ++j) {
+        uint32_t r = (uint32_t)j + draw_below(stream_key(seed, domain, agent, 64 + (uint64_t)j), (uint32_t)(universe - j));
+        uint32_t tmp = perm[(size_t)j];
+        perm[(size_t)j] = perm[r];
+        perm[r] = tmp;
+        mask[perm[(size_t)j] >> 6] |= 1ull << (perm[(size_t)j] & 63);
+    }
+}
+void ramsey_fresh_root(uint64_t seed, uint64_t domain, uint64_t agent, int n, int c, int k, uint8_t *colors,
+                       uint64_t *permitted) {
+    const int E = ramsey_edges(n);
+    for (int e = 0; e < E; ++e) colors[e] = (uint8_t)draw_below(stream_key(seed, domain, agent, 1024 + (uint64_t)e), (uint32_t)c);
+    shuffle_mask(seed, domain, agent, E, ramsey_key_words(n, c), k, permitted);
+}
+void ramsey_generate_roots(uint64_t seed, uint64_t epoch, uint64_t first_agent, int count, int n, int c, int kmin,
+                           int kmax, uint8_t *colors, uint64_t *permitted) {
+    const int E = ramsey_edges(n), KW = ramsey_key_words(n, c);
+    const uint64_t domain = DOMAIN_ROOT ^ (epoch << 32);
+    for (int i = 0; i < count; ++i) {
+        uint64_t agent = first_agent + (uint64_t)i;
+        int k = kmin + (int)draw_below(stream_key(seed, domain, agent, 0), (uint32_t)(kmax - kmin + 1));
+        ramsey_fresh_root(seed, domain, agent, n, c, k, colors + (size_t)i * E, permitted + (size_t)i * KW);
+    }
+}
+
 } // namespace azd

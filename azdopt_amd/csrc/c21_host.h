@@ -23,4 +23,15 @@ void c21_fresh_root(uint64_t seed, uint64_t domain, uint64_t agent, int n, int k
 void c21_generate_roots(uint64_t seed, uint64_t epoch, uint64_t first_agent, int count, int n, int kmin, int kmax,
                         uint8_t *parents, uint64_t *permitted);
 
+// Ramsey space (ramsey_counts/space.rs:40-42): E = N(N-1)/2, ACTION = E*C, STATE = E*(2C+1)
+int ramsey_edges(int n);
+int ramsey_state_dim(int n, int c);
+int ramsey_action_dim(int n, int c);
+int ramsey_key_words(int n, int c);
+void shuffle_mask(uint64_t seed, uint64_t domain, uint64_t agent, int universe, int words, int k, uint64_t *mask);
+void ramsey_fresh_root(uint64_t seed, uint64_t domain, uint64_t agent, int n, int c, int k, uint8_t *colors,
+                       uint64_t *permitted);
+void ramsey_generate_roots(uint64_t seed, uint64_t epoch, uint64_t first_agent, int count, int n, int c, int kmin,
+                           int kmax, uint8_t *colors, uint64_t *permitted);
+
 } // namespace azd

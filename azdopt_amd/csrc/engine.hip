@@ -211,6 +211,34 @@ int sync_status(azd_engine *e) {
 
 int upload_roots(azd_engine *e, const uint8_t *parents, const uint64_t *permitted) {
     const Arenas &a = e->a;
+    if (a.space == SPACE_RAMSEY) {
+        // packed roots: colour of every edge in colex order (E bytes) + permitted edge positions
+        for (int i = 0; i < a.B; ++i) {
+            const uint8_t *col = parents + (size_t)i * a.E;
+            for (int x = 0; x < a.E; ++x)
+                if (col[x] >= a.C) {
+                    g_last_error = "root edge colour out of range";
+                    return AZD_ERR_INVALID_ARGUMENT;
+                }
+            int cnt = 0;
+            for (int w = 0; w < a.KW; ++w) {
+                uint64_t m = permitted[(size_t)i * a.KW + w];
+                int hi = a.E - 64 * w;
+                if ((hi <= 0 && m != 0) || (hi > 0 && hi < 64 && (m >> hi) != 0)) {
+                    g_last_error = "permitted mask has bits beyond the edge count";
+                    return AZD_ERR_INVALID_ARGUMENT;
+                }
+                cnt += __builtin_popcountll(m);
+            }
+            if (cnt * (a.C - 1) > MAX_NODE_ACTIONS) {
+                g_last_error = "more permitted actions than a node can hold";
+                return AZD_ERR_INVALID_ARGUMENT;
+            }
+        }
+        AZD_HIP(hipMemcpyAsync(e->d_stage_parents, parents, (size_t)a.B * a.E, hipMemcpyHostToDevice, e->stream));
+        AZD_HIP(hipMemcpyAsync(e->d_stage_perm, permitted, (size_t)a.B * a.KW * 8, hipMemcpyHostToDevice, e->stream));
+        return AZD_OK;
+    }
     // validate on the host what the kernels assume (parents[v] < v; at most MAX_NODE_ACTIONS permitted)
     for (int i = 0; i < a.B; ++i) {
         const uint8_t *p = parents + (size_t)i * a.n;
@@ -287,6 +315,16 @@ int azd_device_count(void) {
     return n;
 }
 
+int azd_ramsey_state_dim(int n, int n_colors) { return azd::ramsey_state_dim(n, n_colors); }
+int azd_ramsey_action_dim(int n, int n_colors) { return azd::ramsey_action_dim(n, n_colors); }
+int azd_ramsey_key_words(int n, int n_colors) { return azd::ramsey_key_words(n, n_colors); }
+int azd_ramsey_generate_roots(uint64_t seed, uint64_t epoch, uint64_t first_agent, int count, int n, int n_colors, int kmin,
+                              int kmax, uint8_t *colors, uint64_t *permitted) {
+    if (!colors || !permitted || count < 0 || n < 3 || n > AZD_RAMSEY_MAX_N || n_colors < 2 || n_colors > 4) return AZD_ERR_INVALID_ARGUMENT;
+    if (kmin < 0 || kmax < kmin || kmax > azd::ramsey_edges(n)) return AZD_ERR_INVALID_ARGUMENT;
+    azd::ramsey_generate_roots(seed, epoch, first_agent, count, n, n_colors, kmin, kmax, colors, permitted);
+    return AZD_OK;
+}
 int azd_c21_state_dim(int n) { return azd::c21_state_dim(n); }
 int azd_c21_action_dim(int n) { return azd::c21_action_dim(n); }
 int azd_c21_key_words(int n) { return azd::c21_key_words(n); }
@@ -388,7 +426,18 @@ uint64_t azd_evaluator_calls(azd_evaluator *ev) { return ev ? ev->calls : 0; }
 // ------------------------------------------------------------------ engine ABI
 int azd_engine_create(azd_engine **out, const azd_engine_config *cfg, azd_evaluator *ev) {
     if (!out || !cfg) return AZD_ERR_INVALID_ARGUMENT;
-    if (cfg->space_id != AZD_SPACE_C21 || cfg->n < 4 || cfg->n > AZD_C21_MAX_N || cfg->batch <= 0) {
+    const bool ramsey = cfg->space_id == AZD_SPACE_RAMSEY;
+    if (ramsey) {
+        bool ok = cfg->batch > 0 && cfg->n >= 3 && cfg->n <= AZD_RAMSEY_MAX_N && cfg->n_colors >= 2 && cfg->n_colors <= 4;
+        if (ok) {
+            for (int c = 0; c < cfg->n_colors; ++c) ok = ok && cfg->clique_sizes[c] >= 2 && cfg->clique_sizes[c] <= 5;
+            ok = ok && azd::ramsey_edges(cfg->n) <= 256 && azd::ramsey_key_words(cfg->n, cfg->n_colors) <= azd::MAX_KW;
+        }
+        if (!ok) {
+            azd::g_last_error = "unsupported Ramsey space (need 3 <= n, E <= 256, 2..4 colours, clique sizes 2..5, E*C <= 384)";
+            return AZD_ERR_INVALID_ARGUMENT;
+        }
+    } else if (cfg->space_id != AZD_SPACE_C21 || cfg->n < 4 || cfg->n > AZD_C21_MAX_N || cfg->batch <= 0) {
         azd::g_last_error = "unsupported space / n / batch";
         return AZD_ERR_INVALID_ARGUMENT;
     }
@@ -402,11 +451,24 @@ int azd_engine_create(azd_engine **out, const azd_engine_config *cfg, azd_evalua
     azd::Arenas &a = e->a;
     memset(&a, 0, sizeof(a));
     a.n = cfg->n;
-    a.A = azd::c21_action_dim(cfg->n);
-    a.S = azd::c21_state_dim(cfg->n);
-    a.KW = azd::c21_key_words(cfg->n);
     a.B = cfg->batch;
-    a.eval_slope = azd::c21_eval_slope(cfg->n);
+    a.space = ramsey ? azd::SPACE_RAMSEY : azd::SPACE_C21;
+    if (ramsey) {
+        a.C = cfg->n_colors;
+        a.E = azd::ramsey_edges(cfg->n);
+        a.A = azd::ramsey_action_dim(cfg->n, a.C);
+        a.S = azd::ramsey_state_dim(cfg->n, a.C);
+        a.KW = azd::ramsey_key_words(cfg->n, a.C);
+        for (int c = 0; c < a.C; ++c) {
+            a.sizes[c] = cfg->clique_sizes[c];
+            a.cweights[c] = cfg->color_weights[c];
+        }
+    } else {
+        a.A = azd::c21_action_dim(cfg->n);
+        a.S = azd::c21_state_dim(cfg->n);
+        a.KW = azd::c21_key_words(cfg->n);
+        a.eval_slope = azd::c21_eval_slope(cfg->n);
+    }
     if (ev && (ev->state_dim != a.S || ev->action_dim != a.A)) {
         delete e;
         azd::g_last_error = "evaluator dimensions do not match the space";
@@ -459,6 +521,15 @@ int azd_engine_create(azd_engine **out, const azd_engine_config *cfg, azd_evalua
     TRY(e->alloc(&a.weights, B * a.A));
     TRY(e->alloc(&a.argmin, 1));
     TRY(e->alloc(&a.status, 1));
+    if (ramsey) {
+        TRY(e->alloc(&a.root_nbr, B * 128));
+        TRY(e->alloc(&a.cur_nbr, B * 128));
+        TRY(e->alloc(&a.root_counts, B * (size_t)a.C * a.E));
+        TRY(e->alloc(&a.cur_counts, B * (size_t)a.C * a.E));
+        TRY(e->alloc(&a.root_tot, B * 4));
+        TRY(e->alloc(&a.cur_tot, B * 4));
+        TRY(e->alloc(&a.argmin_r, 1));
+    }
     e->persist_enabled = (cfg->flags & AZD_ENGINE_NO_PERSISTENT_STEP) == 0;
     e->barrier_step = (cfg->flags & AZD_ENGINE_ASYNC_STEP) == 0;
     e->log_calls = 1024;
@@ -474,7 +545,7 @@ int azd_engine_create(azd_engine **out, const azd_engine_config *cfg, azd_evalua
         TRY(e->alloc(&e->d_log_key, (size_t)e->log_calls * n_wg));
         TRY(e->alloc(&e->d_log_node, (size_t)e->log_calls * n_wg));
     }
-    TRY(e->alloc(&e->d_stage_parents, B * a.n));
+    TRY(e->alloc(&e->d_stage_parents, B * (size_t)(ramsey ? a.E : a.n)));
     TRY(e->alloc(&e->d_stage_perm, B * a.KW));
     {
         hipError_t he = hipHostMalloc((void **)&e->h_status, sizeof(azd::StatusRec));
@@ -718,6 +789,7 @@ int azd_engine_par_reset_trees(azd_engine *e, const uint8_t *parents, const uint
 // device: no host round trip at the epoch boundary.
 static int c21_policy_args_ok(azd_engine *e, int kmin, int kmax) {
     if (!e || !e->initialised) return AZD_ERR_INVALID_ARGUMENT;
+    if (e->a.space != azd::SPACE_C21) return AZD_ERR_UNSUPPORTED;
     if (kmin < 1 || kmax < kmin || kmax > e->a.A || kmax > azd::MAX_NODE_ACTIONS) return AZD_ERR_INVALID_ARGUMENT;
     return AZD_OK;
 }
@@ -751,8 +823,29 @@ int azd_c21_modify_roots_dev(azd_engine *e, uint64_t seed, uint64_t epoch, int k
     return AZD_OK;
 }
 
+int azd_engine_ramsey_argmin_data(azd_engine *e, azd_ramsey_argmin *out) {
+    if (!e || !out || !e->initialised) return AZD_ERR_INVALID_ARGUMENT;
+    if (e->a.space != azd::SPACE_RAMSEY) return AZD_ERR_UNSUPPORTED;
+    AZD_HIP(hipSetDevice(e->cfg.device));
+    static_assert(sizeof(azd_ramsey_argmin) == sizeof(azd::RamseyArgminRec), "ABI struct mismatch");
+    AZD_HIP(hipStreamSynchronize(e->stream));
+    AZD_HIP(hipMemcpy(out, e->a.argmin_r, sizeof(azd_ramsey_argmin), hipMemcpyDeviceToHost));
+    return AZD_OK;
+}
+int azd_engine_ramsey_agent_counts(azd_engine *e, int agent, int32_t *counts, int32_t *totals) {
+    if (!e || agent < 0 || agent >= e->a.B) return AZD_ERR_INVALID_ARGUMENT;
+    if (e->a.space != azd::SPACE_RAMSEY) return AZD_ERR_UNSUPPORTED;
+    AZD_HIP(hipSetDevice(e->cfg.device));
+    AZD_HIP(hipStreamSynchronize(e->stream));
+    const azd::Arenas &a = e->a;
+    if (counts) AZD_HIP(hipMemcpy(counts, a.cur_counts + (size_t)agent * a.C * a.E, (size_t)a.C * a.E * 4, hipMemcpyDeviceToHost));
+    if (totals) AZD_HIP(hipMemcpy(totals, a.cur_tot + (size_t)agent * 4, 16, hipMemcpyDeviceToHost));
+    return AZD_OK;
+}
+
 int azd_engine_argmin_data(azd_engine *e, azd_argmin *out) {
     if (!e || !out || !e->initialised) return AZD_ERR_INVALID_ARGUMENT;
+    if (e->a.space != azd::SPACE_C21) return AZD_ERR_UNSUPPORTED;
     AZD_HIP(hipSetDevice(e->cfg.device));
     static_assert(sizeof(azd_argmin) == sizeof(azd::ArgminRec), "ABI struct mismatch");
     AZD_HIP(hipMemcpyAsync(e->h_argmin, e->a.argmin, sizeof(azd::ArgminRec), hipMemcpyDeviceToHost, e->stream));
@@ -832,6 +925,25 @@ int azd_engine_agent_state(azd_engine *e, int agent, uint8_t *parents, uint64_t 
     AZD_HIP(hipSetDevice(e->cfg.device));
     AZD_HIP(hipStreamSynchronize(e->stream));
     const azd::Arenas &a = e->a;
+    if (a.space == azd::SPACE_RAMSEY) { // `parents` receives the colour of every edge (E bytes)
+        uint32_t nbr[128];
+        AZD_HIP(hipMemcpy(nbr, a.cur_nbr + (size_t)agent * 128, sizeof(nbr), hipMemcpyDeviceToHost));
+        if (parents) {
+            int pos = 0;
+            for (int v = 0; v < a.n; ++v)
+                for (int u = 0; u < v; ++u, ++pos) {
+                    parents[pos] = 0;
+                    for (int c = 0; c < a.C; ++c)
+                        if ((nbr[c * 32 + v] >> u) & 1u) parents[pos] = (uint8_t)c;
+                }
+        }
+        if (permitted) AZD_HIP(hipMemcpy(permitted, a.cur_perm + (size_t)agent * a.KW, (size_t)a.KW * 8, hipMemcpyDeviceToHost));
+        if (path) AZD_HIP(hipMemcpy(path, a.cur_path + (size_t)agent * a.KW, (size_t)a.KW * 8, hipMemcpyDeviceToHost));
+        if (state_pos) AZD_HIP(hipMemcpy(state_pos, a.state_pos + agent, 4, hipMemcpyDeviceToHost));
+        if (lambda_1) *lambda_1 = 0.0;
+        if (matching_size) *matching_size = 0;
+        return AZD_OK;
+    }
     uint8_t par[azd::PARENTS_STRIDE];
     AZD_HIP(hipMemcpy(par, a.cur_parents + (size_t)agent * azd::PARENTS_STRIDE, azd::PARENTS_STRIDE, hipMemcpyDeviceToHost));
     if (parents) memcpy(parents, par, (size_t)a.n);
@@ -965,6 +1077,7 @@ static bool key_less(const uint64_t *x, const uint64_t *y, int KW) {
 int azd_c21_modify_roots(azd_engine *e, uint64_t seed, uint64_t epoch, int kmin, int kmax, uint8_t *parents_out,
                          uint64_t *permitted_out) {
     if (!e || !parents_out || !permitted_out || !e->initialised) return AZD_ERR_INVALID_ARGUMENT;
+    if (e->a.space != azd::SPACE_C21) return AZD_ERR_UNSUPPORTED;
     AZD_HIP(hipSetDevice(e->cfg.device));
     AZD_HIP(hipStreamSynchronize(e->stream));
     const azd::Arenas &a = e->a;

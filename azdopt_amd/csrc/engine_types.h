@@ -19,7 +19,8 @@ namespace azd {
 constexpr uint32_t NONE = 0xFFFFFFFFu;
 constexpr int PARENTS_STRIDE = 32; // bytes per packed parents row on the device
 constexpr int MAX_N = 24;
-constexpr int MAX_KW = 4;
+constexpr int MAX_KW = 6;                   // c21 uses up to 4 key words, the Ramsey space up to 6
+constexpr int SPACE_C21 = 1, SPACE_RAMSEY = 2; // = AZD_SPACE_* of include/azdopt_amd.h
 constexpr int PRED_CHUNKS = 2;               // a node holds at most 64*PRED_CHUNKS legal actions
 constexpr int MAX_NODE_ACTIONS = 64 * PRED_CHUNKS;
 constexpr int FRONTIER_CAP = 256;            // LDS-staged cascade frontier per tree
@@ -76,6 +77,15 @@ struct ArgminRec { // device copy of azd_argmin
     uint32_t node;
 };
 
+struct RamseyArgminRec { // device copy of azd_ramsey_argmin
+    uint8_t colors[256];
+    uint64_t permitted[4];
+    int32_t totals[4];
+    float eval;
+    int32_t agent;
+    uint32_t node;
+};
+
 struct StatusRec { // small device block copied back after every host-visible call
     unsigned long long improved;   // k_argmin calls that improved the argmin
     unsigned long long expansions; // sum over agents and calls (metric numerator)
@@ -112,6 +122,15 @@ struct Arenas {
     StatusRec *status;
     int n, A, S, KW, B;
     float eval_slope;       // squish slope 1/(C_UPPER - C_LOWER), 04-c21-tree.rs:58-74
+    // ---- Ramsey space (space_ramsey.inc); unused (null / 0) for c21
+    int space;              // SPACE_C21 / SPACE_RAMSEY
+    int C, E;               // colours, edges N(N-1)/2;  A = E*C, S = E*(2C+1)
+    int sizes[4];           // clique size per colour (2..5)
+    float cweights[4];      // weight per colour in evaluate
+    uint32_t *root_nbr, *cur_nbr;      // [B][4*32] neighbourhood bitsets per colour
+    int32_t *root_counts, *cur_counts; // [B][C*E]
+    int32_t *root_tot, *cur_tot;       // [B][4]
+    RamseyArgminRec *argmin_r;
 };
 
 // what the persistent step needs to run the evaluator inside the kernel
@@ -157,5 +176,15 @@ void launch_hash_predictions(float *d_out, int batch, int action_dim, uint64_t s
 void launch_probe_cost(const uint8_t *d_parents, int n, int count, int reps, int full, double *d_lam, int *d_mu,
                        void *stream);
 void launch_probe_math(const float *d_in, float *d_out, int n, void *stream); // sqrtf / sub parity probe (tests)
+
+// the same launchers for SPACE_RAMSEY (ramsey_kernels.hip); the functions above forward to them
+void ramsey_launch_init_roots(const Arenas &a, const uint8_t *d_colors, const uint64_t *d_permitted, void *stream);
+void ramsey_launch_add_actions(const Arenas &a, int root_mode, void *stream);
+void ramsey_launch_rollout(const Arenas &a, const TolTable &tol, void *stream);
+void ramsey_launch_argmin(const Arenas &a, int init_mode, void *stream);
+void ramsey_launch_observe(const Arenas &a, uint32_t n_obs_tol, void *stream);
+bool ramsey_persist_plan(const Arenas &a, const FusedEval &ev, uint32_t *dyn_stride, size_t *dyn_bytes);
+void ramsey_launch_persist(const Arenas &a, const PersistArgs *d_args, int n_calls, unsigned long long *log_key,
+                           uint32_t *log_node, uint32_t dyn_stride, size_t dyn_bytes, void *stream);
 
 } // namespace azd

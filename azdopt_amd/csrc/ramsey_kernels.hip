@@ -1,0 +1,97 @@
+// ramsey_kernels.hip -- Ramsey translation unit of the data-parallel tree-search step on gfx950:
+// tree_core.inc instantiated with the RamseySpace policy (space_ramsey.inc), the CU-resident
+// persistent step and the launchers the c21 entry points forward to for SPACE_RAMSEY.
+// Built with -ffp-contract=off like the c21 unit.
+#include <hip/hip_runtime.h>
+
+#include "engine_types.h"
+
+namespace azd {
+
+#include "tree_core.inc"
+#include "space_ramsey.inc"
+
+#define DISPATCH_RKW(A, FN, ...)                                  \
+    switch ((A).KW) {                                             \
+    case 1: FN<RamseySpace<1>>(__VA_ARGS__); break;               \
+    case 2: FN<RamseySpace<2>>(__VA_ARGS__); break;               \
+    case 3: FN<RamseySpace<3>>(__VA_ARGS__); break;               \
+    case 4: FN<RamseySpace<4>>(__VA_ARGS__); break;               \
+    case 5: FN<RamseySpace<5>>(__VA_ARGS__); break;               \
+    default: FN<RamseySpace<6>>(__VA_ARGS__); break;              \
+    }
+
+#include "persistent_step.inc"
+
+template <class SP>
+static void l_init_roots(const Arenas &a, const uint8_t *p, const uint64_t *m, hipStream_t st) {
+    k_init_roots<SP><<<dim3(a.B), dim3(64), SP::dyn_bytes(a), st>>>(a, p, m);
+}
+template <class SP>
+static void l_add_actions(const Arenas &a, int root_mode, hipStream_t st) {
+    k_add_actions<SP><<<dim3(a.B), dim3(64), SP::dyn_bytes(a), st>>>(a, root_mode);
+}
+template <class SP>
+static void l_rollout(const Arenas &a, const TolTable &tol, hipStream_t st) {
+    k_rollout<SP><<<dim3(a.B), dim3(64), SP::dyn_bytes(a), st>>>(a, tol);
+}
+template <class SP>
+static void l_argmin(const Arenas &a, int init_mode, hipStream_t st) {
+    k_argmin<SP><<<dim3(1), dim3(1024), SP::dyn_bytes(a), st>>>(a, init_mode);
+}
+template <class SP>
+static void l_observe(const Arenas &a, uint32_t tol, hipStream_t st) {
+    k_observe<SP><<<dim3(a.B), dim3(64), SP::dyn_bytes(a), st>>>(a, tol);
+}
+template <class SP>
+static void l_persist(const Arenas &a, const PersistArgs *d_args, int n_calls, unsigned long long *log_key,
+                      uint32_t *log_node, uint32_t dyn_stride, size_t dyn_bytes, hipStream_t st) {
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute((const void *)k_persist<SP>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 24 * 1024);
+        attr_set = true;
+    }
+    const int n_wg = (a.B + PERSIST_WAVES - 1) / PERSIST_WAVES;
+    k_persist<SP><<<dim3(n_wg), dim3(PERSIST_WAVES * 64), dyn_bytes, st>>>(d_args, n_calls, log_key, log_node, dyn_stride);
+    k_argmin_log<SP><<<dim3(1), dim3(64), SP::dyn_bytes(a), st>>>(a, n_calls, n_wg, log_key, log_node);
+}
+
+void ramsey_launch_init_roots(const Arenas &a, const uint8_t *d_colors, const uint64_t *d_permitted, void *stream) {
+    DISPATCH_RKW(a, l_init_roots, a, d_colors, d_permitted, (hipStream_t)stream);
+}
+void ramsey_launch_add_actions(const Arenas &a, int root_mode, void *stream) {
+    DISPATCH_RKW(a, l_add_actions, a, root_mode, (hipStream_t)stream);
+}
+void ramsey_launch_rollout(const Arenas &a, const TolTable &tol, void *stream) {
+    DISPATCH_RKW(a, l_rollout, a, tol, (hipStream_t)stream);
+}
+void ramsey_launch_argmin(const Arenas &a, int init_mode, void *stream) {
+    DISPATCH_RKW(a, l_argmin, a, init_mode, (hipStream_t)stream);
+}
+void ramsey_launch_observe(const Arenas &a, uint32_t n_obs_tol, void *stream) {
+    DISPATCH_RKW(a, l_observe, a, n_obs_tol, (hipStream_t)stream);
+}
+// LDS plan of the persistent step; false when the workgroup does not fit a CU or the in-kernel MLP
+// cannot take the layer widths (it loads rows as float4)
+bool ramsey_persist_plan(const Arenas &a, const FusedEval &ev, uint32_t *dyn_stride, size_t *dyn_bytes) {
+    size_t per = CORE_DYN_BYTES + (size_t)a.C * a.E * sizeof(int32_t);
+    size_t stride = (per + 15) & ~(size_t)15;
+    size_t total = stride * PERSIST_WAVES;
+    if (ev.kind == 3) {
+        for (int l = 0; l < ev.n_layers; ++l)
+            if (ev.dims[l] % 4 != 0) return false;
+        size_t mlp = (size_t)PERSIST_WAVES * ((size_t)(ev.dims[0] + 4) + 2 * (size_t)(ev.max_hidden + 4)) * sizeof(float);
+        if (mlp > total) total = mlp;
+    }
+    const size_t static_lds = PERSIST_WAVES * (sizeof(RamseyLds) + 16) + 256;
+    if (total + static_lds > 160 * 1024 - 24 * 1024) return false;
+    *dyn_stride = (uint32_t)stride;
+    *dyn_bytes = total;
+    return true;
+}
+void ramsey_launch_persist(const Arenas &a, const PersistArgs *d_args, int n_calls, unsigned long long *log_key,
+                           uint32_t *log_node, uint32_t dyn_stride, size_t dyn_bytes, void *stream) {
+    DISPATCH_RKW(a, l_persist, a, d_args, n_calls, log_key, log_node, dyn_stride, dyn_bytes, (hipStream_t)stream);
+}
+
+} // namespace azd

@@ -56,6 +56,7 @@ void launch_async(const Arenas &a, const PersistArgs *d_args, int n_calls, unsig
 // LDS plan of the asynchronous step (no evaluator buffers in LDS)
 bool async_plan(const Arenas &a, const FusedEval &ev, uint32_t *dyn_stride, size_t *dyn_bytes) {
     (void)ev;
+    if (a.space != SPACE_C21) return false; // the asynchronous step is built for the c21 space only
     if (a.B > 65536 || a.node_cap > 65536) return false; // (agent, node) are packed 16 + 16 bits in the argmin log
     size_t stride = (dyn_lds_bytes(a.n) + 15) & ~(size_t)15;
     size_t total = stride * PERSIST_WAVES;
@@ -128,18 +129,23 @@ static void l_observe(const Arenas &a, uint32_t tol, hipStream_t st) {
 }
 
 void launch_init_roots(const Arenas &a, const uint8_t *d_parents, const uint64_t *d_permitted, void *stream) {
+    if (a.space == SPACE_RAMSEY) return ramsey_launch_init_roots(a, d_parents, d_permitted, stream);
     DISPATCH_KW(a, l_init_roots, a, d_parents, d_permitted, (hipStream_t)stream);
 }
 void launch_add_actions(const Arenas &a, int root_mode, void *stream) {
+    if (a.space == SPACE_RAMSEY) return ramsey_launch_add_actions(a, root_mode, stream);
     DISPATCH_KW(a, l_add_actions, a, root_mode, (hipStream_t)stream);
 }
 void launch_rollout(const Arenas &a, const TolTable &tol, void *stream) {
+    if (a.space == SPACE_RAMSEY) return ramsey_launch_rollout(a, tol, stream);
     DISPATCH_KW(a, l_rollout, a, tol, (hipStream_t)stream);
 }
 void launch_argmin(const Arenas &a, int init_mode, void *stream) {
+    if (a.space == SPACE_RAMSEY) return ramsey_launch_argmin(a, init_mode, stream);
     DISPATCH_KW(a, l_argmin, a, init_mode, (hipStream_t)stream);
 }
 void launch_observe(const Arenas &a, uint32_t n_obs_tol, void *stream) {
+    if (a.space == SPACE_RAMSEY) return ramsey_launch_observe(a, n_obs_tol, stream);
     DISPATCH_KW(a, l_observe, a, n_obs_tol, (hipStream_t)stream);
 }
 template <class SP>
@@ -158,7 +164,10 @@ static void l_persist(const Arenas &a, const PersistArgs *d_args, int n_calls, u
 bool persist_plan(const Arenas &a, const FusedEval &ev, uint32_t *dyn_stride, size_t *dyn_bytes) {
     size_t stride = (dyn_lds_bytes(a.n) + 15) & ~(size_t)15;
     size_t total = stride * PERSIST_WAVES;
+    if (a.space == SPACE_RAMSEY) return ramsey_persist_plan(a, ev, dyn_stride, dyn_bytes);
     if (ev.kind == 3) {
+        for (int l = 0; l < ev.n_layers; ++l)
+            if (ev.dims[l] % 4 != 0) return false; // the in-kernel MLP loads rows as float4
         size_t mlp = (size_t)PERSIST_WAVES * ((size_t)(ev.dims[0] + 4) + 2 * (size_t)(ev.max_hidden + 4)) * sizeof(float);
         if (mlp > total) total = mlp;
     }
@@ -170,6 +179,7 @@ bool persist_plan(const Arenas &a, const FusedEval &ev, uint32_t *dyn_stride, si
 }
 void launch_persist(const Arenas &a, const PersistArgs *d_args, int n_calls, unsigned long long *log_key,
                     uint32_t *log_node, uint32_t dyn_stride, size_t dyn_bytes, void *stream) {
+    if (a.space == SPACE_RAMSEY) return ramsey_launch_persist(a, d_args, n_calls, log_key, log_node, dyn_stride, dyn_bytes, stream);
     DISPATCH_KW(a, l_persist, a, d_args, n_calls, log_key, log_node, dyn_stride, dyn_bytes, (hipStream_t)stream);
 }
 template <class SP>

@@ -18,6 +18,17 @@ class ArgminData:
         self.agent, self.node = rec.agent, rec.node
 
 
+class RamseyArgminData:
+    """az-discrete-opt/src/log.rs:1-11 for the Ramsey space: state = colouring + permitted edges,
+    cost = TotalCounts"""
+
+    def __init__(self, rec, space):
+        self.state = dict(colors=np.array(rec.colors[:space.E], np.uint8), permitted=np.array(rec.permitted[:], np.uint64))
+        self.cost = dict(clique_counts=[int(x) for x in rec.totals[:space.C]])
+        self.eval = np.float32(rec.eval)
+        self.agent, self.node = rec.agent, rec.node
+
+
 class TreeView:
     """Raw arrays of one SearchTree (tree/mod.rs:28-32): nodes, arcs, predictions, keys."""
     FIELDS = ("c", "c_star", "n_t", "exhausted", "act_begin", "act_end", "keys", "e_src", "e_dst", "e_pp",
@@ -43,6 +54,11 @@ class NablaOptimizer:
         cfg = _lib.EngineConfig(space.SPACE_ID, space.n, batch, device, node_capacity, arc_capacity,
                                 prediction_capacity, first_agent,
                                 (0 if persistent else _lib.ENGINE_NO_PERSISTENT_STEP) | (_lib.ENGINE_ASYNC_STEP if async_step else 0))
+        if space.SPACE_ID == _lib.SPACE_RAMSEY:
+            cfg.n_colors = space.C
+            for i in range(space.C):
+                cfg.clique_sizes[i] = space.sizes[i]
+                cfg.color_weights[i] = space.weights[i]
         self._h = C.c_void_p()
         ev = model._h if model is not None else None
         _lib.check(self._L.azd_engine_create(C.byref(self._h), C.byref(cfg), ev), "azd_engine_create")
@@ -63,7 +79,7 @@ class NablaOptimizer:
         return opt
 
     def _roots(self, parents, permitted):
-        parents = np.ascontiguousarray(parents, np.uint8).reshape(self.batch, self.space.n)
+        parents = np.ascontiguousarray(parents, np.uint8).reshape(self.batch, self.space.ROOT_BYTES)
         permitted = np.ascontiguousarray(permitted, np.uint64).reshape(self.batch, self.space.KEY_WORDS)
         return parents, permitted
 
@@ -115,6 +131,10 @@ class NablaOptimizer:
 
     def argmin_data(self):
         """optimizer/mod.rs:361"""
+        if self.space.SPACE_ID == _lib.SPACE_RAMSEY:
+            rec = _lib.RamseyArgmin()
+            _lib.check(self._L.azd_engine_ramsey_argmin_data(self._h, C.byref(rec)), "ramsey_argmin_data")
+            return RamseyArgminData(rec, self.space)
         rec = _lib.Argmin()
         _lib.check(self._L.azd_engine_argmin_data(self._h, C.byref(rec)), "argmin_data")
         return ArgminData(rec, self.space.n, self.space.KEY_WORDS)
@@ -196,13 +216,20 @@ class NablaOptimizer:
         return [self.get_tree(i) for i in range(self.batch)]
 
     def agent_state(self, agent):
-        parents = np.zeros(self.space.n, np.uint8)
+        parents = np.zeros(self.space.ROOT_BYTES, np.uint8)
         permitted = np.zeros(self.space.KEY_WORDS, np.uint64)
         path = np.zeros(self.space.KEY_WORDS, np.uint64)
         pos, lam, mu = C.c_uint32(), C.c_double(), C.c_int32()
         _lib.check(self._L.azd_engine_agent_state(self._h, agent, _lib.ptr(parents), _lib.ptr(permitted), _lib.ptr(path),
                                                   C.byref(pos), C.byref(lam), C.byref(mu)), "agent_state")
         return dict(parents=parents, permitted=permitted, path=path, state_pos=pos.value, lambda1=lam.value, matching=mu.value)
+
+    def ramsey_agent_counts(self, agent):
+        """live (counts [C, E], totals [C]) of an agent's RamseyCounts state"""
+        counts = np.zeros((self.space.C, self.space.E), np.int32)
+        totals = np.zeros(4, np.int32)
+        _lib.check(self._L.azd_engine_ramsey_agent_counts(self._h, agent, _lib.ptr(counts), _lib.ptr(totals)), "ramsey_agent_counts")
+        return counts, totals[:self.space.C]
 
     def counters(self):
         out = np.zeros(_lib.CTR_COUNT, np.uint64)

@@ -41,6 +41,10 @@ class ROTModifyParentsOnce(ActionsNeverRepeat, ActionOrderIndependent):
         self.ACTION_DIM = L.azd_c21_action_dim(self.n)  # space.rs:48
         self.KEY_WORDS = L.azd_c21_key_words(self.n)
 
+    @property
+    def ROOT_BYTES(self):
+        return self.n
+
     def default_permitted_range(self):
         """04-c21-tree.rs:85: 5..=(ACTION / 2), clamped for tiny N"""
         hi = max(1, self.ACTION_DIM // 2)
@@ -65,3 +69,49 @@ class ROTModifyParentsOnce(ActionsNeverRepeat, ActionOrderIndependent):
         while c * (c + 1) // 2 - 1 <= index:
             c += 1
         return index - (c * (c - 1) // 2 - 1), c
+
+
+class RamseySpaceNoEdgeRecolor(ActionsNeverRepeat, ActionOrderIndependent):
+    """Ramsey space: C-colourings of the edges of K_N, an action recolours one still-permitted edge
+    (graph-state/src/ramsey_counts/space.rs:10-176; axioms asserted at :179-186).
+    cost = TotalCounts (monochromatic `sizes[c]`-cliques per colour); evaluate = sum_c count_c * w_c;
+    g = c_s h + r (1 - h), h_sa = 1 - c*/c (:159-177).  Drivers: 01-r333.rs (N 16, [3,3,3]),
+    02-r44.rs (N 17, [4,4])."""
+
+    SPACE_ID = _lib.SPACE_RAMSEY
+
+    def __init__(self, n, sizes, weights=None):
+        self.n = int(n)
+        self.sizes = [int(x) for x in sizes]
+        self.weights = [1.0] * len(self.sizes) if weights is None else [float(x) for x in weights]
+        self.C = len(self.sizes)
+        self.E = self.n * (self.n - 1) // 2
+        L = _lib.lib()
+        self.STATE_DIM = L.azd_ramsey_state_dim(self.n, self.C)    # space.rs:40
+        self.ACTION_DIM = L.azd_ramsey_action_dim(self.n, self.C)  # space.rs:42
+        self.KEY_WORDS = L.azd_ramsey_key_words(self.n, self.C)
+
+    @property
+    def ROOT_BYTES(self):
+        return self.E
+
+    def default_permitted_range(self):
+        """02-r44.rs:83: 12..=(E / 2), clamped to what one node can hold"""
+        hi = max(1, min(self.E // 2, 128 // (self.C - 1)))
+        return min(12, hi), hi
+
+    def generate_roots(self, seed, count, first_agent=0, epoch=0, kmin=None, kmax=None):
+        """`init_state` of the drivers with a seeded generator.  Returns packed roots:
+        colors u8 [count, E], permitted edges u64 [count, KEY_WORDS]."""
+        lo, hi = self.default_permitted_range()
+        kmin = lo if kmin is None else kmin
+        kmax = hi if kmax is None else kmax
+        colors = np.zeros((count, self.E), np.uint8)
+        permitted = np.zeros((count, self.KEY_WORDS), np.uint64)
+        _lib.check(_lib.lib().azd_ramsey_generate_roots(seed, epoch, first_agent, count, self.n, self.C, kmin, kmax,
+                                                        _lib.ptr(colors), _lib.ptr(permitted)), "azd_ramsey_generate_roots")
+        return colors, permitted
+
+    def action(self, index):
+        """(edge position, new colour) of action `index` (space.rs:48-54)"""
+        return index % self.E, index // self.E

@@ -67,6 +67,27 @@ int azd_c21_generate_roots(uint64_t seed, uint64_t epoch, uint64_t first_agent, 
                            int kmin, int kmax, uint8_t *parents, uint64_t *permitted);
 
 /* ------------------------------------------------------------------------- */
+/* Space seam: Ramsey = RamseySpaceNoEdgeRecolor<B32, N, E, C>               */
+/*   graph-state/src/ramsey_counts/space.rs:10-176 (drivers 01-r333.rs,      */
+/*   02-r44.rs): E = N(N-1)/2 edges in colex order (simple_graph/edge.rs),   */
+/*   action id = edge + new_colour * E.  Built for E <= 256, 2..4 colours,   */
+/*   clique sizes 2..5, E*C <= 384 (r333: N=16, r44: N=17).                  */
+/* ------------------------------------------------------------------------- */
+#define AZD_SPACE_RAMSEY 2
+#define AZD_RAMSEY_MAX_N 23
+int azd_ramsey_state_dim(int n, int n_colors);  /* E(2C+1)  space.rs:40 */
+int azd_ramsey_action_dim(int n, int n_colors); /* EC       space.rs:42 */
+int azd_ramsey_key_words(int n, int n_colors);
+/* Host-side `init_state` closure of the drivers (01-r333.rs:84-90: ColoredCompleteBitsetGraph::
+ * generate with uniform colour weights + RamseyCountsNoRecolor::generate), seeded.
+ * Packed root format of this space, passed through the same `parents` / `permitted`
+ * arguments of the engine calls below:
+ *   colors    [count][E]  u8   colour of the edge at each colex position
+ *   permitted [count][KW] u64  bit e set <=> edge position e may still be recoloured */
+int azd_ramsey_generate_roots(uint64_t seed, uint64_t epoch, uint64_t first_agent, int count, int n,
+                              int n_colors, int kmin, int kmax, uint8_t *colors, uint64_t *permitted);
+
+/* ------------------------------------------------------------------------- */
 /* Evaluator seam (NablaModel)                                               */
 /* ------------------------------------------------------------------------- */
 typedef struct azd_evaluator azd_evaluator;
@@ -124,8 +145,8 @@ uint64_t azd_evaluator_calls(azd_evaluator *ev);
 typedef struct azd_engine azd_engine;
 
 typedef struct azd_engine_config {
-    int space_id;      /* AZD_SPACE_C21 */
-    int n;             /* vertices N of the c21 space (4..AZD_C21_MAX_N) */
+    int space_id;      /* AZD_SPACE_C21 or AZD_SPACE_RAMSEY */
+    int n;             /* vertices N (c21: 4..AZD_C21_MAX_N; Ramsey: 3..AZD_RAMSEY_MAX_N) */
     int batch;         /* BATCH: agents (trees) owned by this engine / GPU */
     int device;        /* HIP device ordinal */
     /* per-tree arena capacities; 0 = default sized for 800 calls per epoch */
@@ -134,6 +155,10 @@ typedef struct azd_engine_config {
     int prediction_capacity;
     uint64_t first_agent; /* global id of agent 0 (multi-GPU sharding) */
     uint32_t flags;       /* AZD_ENGINE_* */
+    /* AZD_SPACE_RAMSEY only (RamseySpaceNoEdgeRecolor::new(sizes, weights), space.rs:17-24) */
+    int n_colors;         /* C */
+    int clique_sizes[4];  /* SIZES: forbidden clique size per colour */
+    float color_weights[4];
 } azd_engine_config;
 
 /* run every phase of a call as its own kernel launch instead of the CU-resident persistent step
@@ -155,6 +180,16 @@ typedef struct azd_argmin {
     int32_t agent;             /* tree the state was found in */
     uint32_t node;             /* its node index in that tree */
 } azd_argmin;
+
+/* ArgminData<RamseyCountsNoRecolor, TotalCounts<C>> for the Ramsey space */
+typedef struct azd_ramsey_argmin {
+    uint8_t colors[256];       /* colour per colex edge position */
+    uint64_t permitted[4];     /* permitted edge positions */
+    int32_t totals[4];         /* TotalCounts: monochromatic cliques per colour */
+    float eval;
+    int32_t agent;
+    uint32_t node;
+} azd_ramsey_argmin;
 
 enum { /* indices into azd_engine_counters' output */
     AZD_CTR_EXPANSIONS = 0,     /* calls that ended on a new non-terminal node (metric numerator) */
@@ -212,6 +247,9 @@ int azd_engine_par_update_model(azd_engine *e, uint32_t n_obs_tol, float *loss);
 int azd_engine_par_reset_trees(azd_engine *e, const uint8_t *parents, const uint64_t *permitted);
 /* NablaOptimizer::argmin_data (optimizer/mod.rs:361) */
 int azd_engine_argmin_data(azd_engine *e, azd_argmin *out);
+int azd_engine_ramsey_argmin_data(azd_engine *e, azd_ramsey_argmin *out); /* AZD_SPACE_RAMSEY engines */
+/* the agent's live per-edge clique counts [C][E] and totals [4] (RamseyCounts, mod.rs:12-17) */
+int azd_engine_ramsey_agent_counts(azd_engine *e, int agent, int32_t *counts, int32_t *totals);
 
 /* The `modify_root` policy of the c21 driver (04-c21-tree.rs:172-206), seeded;
  * reads each tree's node_data() (tree/mod.rs:302-307) and writes new packed roots. */

@@ -1,0 +1,142 @@
+"""GPU parity of the Ramsey colour-reassignment space against the CPU oracle:
+exported trees, state vectors, live clique counts, observations, argmin and counters must agree
+bit-for-bit (integer / index work; the three f32 formulas evaluate, g and h_sa are single IEEE ops)."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+MAIN_CTRS = ["EXPANSIONS", "TERMINALS", "TRANSPOSITIONS", "VISITED_STEPS", "SELECT_CALLS", "SUM_DEG", "SUM_ACTIONS",
+             "CASCADE_NODES", "NEW_PREDS", "ROOT_EXHAUSTED", "MAX_FRONTIER", "MAX_DEPTH", "CURIOSITY_PAIRS"]
+
+
+@pytest.fixture(scope="module")
+def az():
+    import azdopt_amd
+    if azdopt_amd.device_count() < 1:
+        pytest.fail("no gfx950 device: the GPU tests need the HIP path")
+    return azdopt_amd
+
+
+def assert_tree_equal(tg, to, tag=""):
+    for f in to.FIELDS:
+        a, b = getattr(tg, f), getattr(to, f)
+        assert a.shape == b.shape, (tag, f, a.shape, b.shape)
+        if a.dtype.kind == "f":
+            assert np.array_equal(a.view(np.uint32), b.view(np.uint32)), (tag, f)
+        else:
+            assert np.array_equal(a.astype(np.int64), b.astype(np.int64)), (tag, f)
+
+
+def run_ramsey_parity(az, orc, n, sizes, weights, B, kmin, kmax, tol, steps, epochs, seed, n_obs_tol, check_every=1,
+                      sample=None, first_agent=0, threads=8, persistent=True):
+    space = az.RamseySpaceNoEdgeRecolor(n, sizes, weights)
+    C = len(sizes)
+    model = az.HashStreamModel(space.STATE_DIM, space.ACTION_DIM, seed, first_agent)
+    colors, permitted = space.generate_roots(seed, B, first_agent=first_agent, kmin=kmin, kmax=kmax)
+    co, mo = orc.gen_ramsey_roots(seed, 0, first_agent, B, n, C, kmin, kmax)
+    assert np.array_equal(colors, co) and np.array_equal(permitted, mo)
+    opt = az.NablaOptimizer.par_new(space, (colors, permitted), model, B, first_agent=first_agent, persistent=persistent)
+    oe = orc.Engine(n, B, threads=threads, ramsey=(sizes, weights))
+    assert (oe.S, oe.A, oe.KW) == (space.STATE_DIM, space.ACTION_DIM, space.KEY_WORDS)
+    oe.new_begin(colors, permitted)
+    call = 0
+    oe.new_end(orc.hash_predictions(seed, first_agent, B, space.ACTION_DIM, call))
+    agents = range(B) if sample is None else sample
+
+    def compare(tag):
+        assert np.array_equal(opt.state_vecs(), oe.state_vecs()), tag
+        for i in agents:
+            assert_tree_equal(opt.get_tree(i), oe.export_tree(i), f"{tag} agent {i}")
+            sg, so = opt.agent_state(i), oe.agent_state(i)
+            for k in ("parents", "permitted", "path", "state_pos"):
+                assert np.array_equal(sg[k], so[k]), (tag, i, k, sg[k], so[k])
+            cg, tg = opt.ramsey_agent_counts(i)
+            assert np.array_equal(cg, oe.agent_counts(i)), (tag, i)
+        ag, ao = opt.argmin_data(), oe.argmin()
+        assert np.array_equal(ag.state["colors"], ao["parents"]), tag
+        pw = min(4, space.KEY_WORDS)  # permitted EDGES: E <= 256 bits
+        assert np.array_equal(ag.state["permitted"][:pw], ao["permitted"][:pw]) and not ao["permitted"][pw:].any(), tag
+        assert ag.eval.tobytes() == ao["eval"].tobytes(), (tag, ag.eval, ao["eval"])
+        assert ag.cost["clique_counts"] == oe.argmin_totals()[:C].tolist(), tag
+        cg, co_ = opt.counters(), oe.counters()
+        for k in MAIN_CTRS:
+            assert cg[k] == co_[k], (tag, k, cg[k], co_[k])
+
+    compare("par_new")
+    for epoch in range(epochs):
+        s = 0
+        while s < steps:
+            k = min(check_every, steps - s)
+            improved_g = opt.par_roll_out_episodes(tol, n_calls=k)
+            improved_o = 0
+            for _ in range(k):
+                oe.rollout_begin(*tol)
+                call += 1
+                improved_o += oe.rollout_end(orc.hash_predictions(seed, first_agent, B, space.ACTION_DIM, call))
+            assert improved_g == improved_o, (epoch, s, improved_g, improved_o)
+            s += k
+            compare(f"epoch {epoch} step {s}")
+        sv, obs, w = opt.observe(n_obs_tol)
+        oo, ow = oe.observe(n_obs_tol)
+        # h_sa = 1 - c*/c is NaN for a child with c = c* = 0 (a monochromatic-clique-free colouring: the
+        # drivers stop there); NaN payloads are not part of the contract, everything else is bit-exact
+        nan = np.isnan(oo)
+        assert np.array_equal(np.isnan(obs), nan) and np.array_equal(w, ow)
+        assert np.array_equal(obs[~nan].view(np.uint32), oo[~nan].view(np.uint32))
+        assert np.array_equal(sv, oe.state_vecs())
+        ro = oe.modify_roots(seed, epoch, first_agent, kmin, kmax)  # the drivers' modify_root policy (02-r44.rs:196-228)
+        opt.par_reset_trees(ro)
+        oe.reset_begin(*ro)
+        call += 1
+        oe.reset_end(orc.hash_predictions(seed, first_agent, B, space.ACTION_DIM, call))
+        compare(f"epoch {epoch} reset")
+    return opt.counters()
+
+
+def test_ramsey_triangles_two_colours_every_step(az, orc):
+    c = run_ramsey_parity(az, orc, 6, [3, 3], [1.0, 1.0], B=24, kmin=3, kmax=7, tol=([6, 3, 2], 1), steps=60, epochs=2,
+                          seed=1, n_obs_tol=2)
+    assert c["TERMINALS"] > 0 and c["TRANSPOSITIONS"] > 0 and c["FAILED"] == 0
+
+
+@pytest.mark.parametrize("persistent", [True, False])
+def test_ramsey_k4_and_weights_all_branches(az, orc, persistent):
+    c = run_ramsey_parity(az, orc, 9, [4, 3], [1.0, 0.5], B=48, kmin=3, kmax=8, tol=([8, 4, 2], 1), steps=120, epochs=2,
+                          seed=2, n_obs_tol=3, check_every=7, persistent=persistent)
+    assert c["TERMINALS"] > 0 and c["TRANSPOSITIONS"] > 0 and c["VISITED_STEPS"] > 0 and c["FAILED"] == 0
+
+
+def test_ramsey_k5_three_colours(az, orc):
+    run_ramsey_parity(az, orc, 10, [3, 4, 5], [1.0, 1.0, 2.0], B=32, kmin=4, kmax=10, tol=([10, 5, 3], 2), steps=150, epochs=1,
+                      seed=3, n_obs_tol=4, check_every=25)
+
+
+def test_ramsey_r333_reference_hyperparameters(az, orc):
+    """01-r333.rs: N = 16, three colours, triangles; n_as_tol table of the driver (:128-130)"""
+    tol = ([200, 200, 200, 100, 100, 100, 50, 50, 50, 25, 25, 25], 10)
+    c = run_ramsey_parity(az, orc, 16, [3, 3, 3], [1.0, 1.0, 1.0], B=64, kmin=10, kmax=60, tol=tol, steps=400, epochs=1, seed=0,
+                          n_obs_tol=200, check_every=100, sample=range(0, 64, 7))
+    assert c["EXPANSIONS"] > 0 and c["FAILED"] == 0
+
+
+def test_ramsey_r44_reference_hyperparameters(az, orc):
+    """02-r44.rs: N = 17, two colours, K4; n_as_tol table of the driver (:128-130)"""
+    tol = ([200, 200, 100, 100, 50, 50, 25, 25], 10)
+    c = run_ramsey_parity(az, orc, 17, [4, 4], [1.0, 1.0], B=64, kmin=12, kmax=68, tol=tol, steps=400, epochs=1, seed=1,
+                          n_obs_tol=200, check_every=100, sample=range(0, 64, 7))
+    assert c["EXPANSIONS"] > 0 and c["FAILED"] == 0
+
+
+def test_ramsey_invalid_roots_rejected(az):
+    space = az.RamseySpaceNoEdgeRecolor(6, [3, 3])
+    model = az.HashStreamModel(space.STATE_DIM, space.ACTION_DIM, 0, 0)
+    colors, permitted = space.generate_roots(0, 4, kmin=3, kmax=5)
+    bad = colors.copy()
+    bad[1, 2] = 2  # colour out of range
+    with pytest.raises(az.AzdError):
+        az.NablaOptimizer.par_new(space, (bad, permitted), model, 4)
+    badp = permitted.copy()
+    badp[0, 0] |= np.uint64(1 << 20)  # beyond E = 15
+    with pytest.raises(az.AzdError):
+        az.NablaOptimizer.par_new(space, (colors, badp), model, 4)
