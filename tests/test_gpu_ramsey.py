@@ -140,3 +140,39 @@ def test_ramsey_invalid_roots_rejected(az):
     badp[0, 0] |= np.uint64(1 << 20)  # beyond E = 15
     with pytest.raises(az.AzdError):
         az.NablaOptimizer.par_new(space, (colors, badp), model, 4)
+
+
+@pytest.mark.parametrize("persistent", [True, False])
+def test_ramsey_topology_parity_with_mlp_predictions(az, orc, persistent):
+    """r333 end-to-end with the real MLP (STATE 840 is not a multiple of 16: exercises the K tail of the
+    in-kernel MFMA evaluator): the oracle is fed the GPU's predictions, trees must match bit-for-bit, and
+    the predictions themselves must match the oracle's fp32 MLP on the same state vectors."""
+    n, sizes, B, seed = 16, [3, 3, 3], 40, 6  # 40 = 2.5 workgroups of 16 agents
+    tol = ([200, 200, 200, 100, 100, 100, 50, 50, 50, 25, 25, 25], 10)
+    space = az.RamseySpaceNoEdgeRecolor(n, sizes)
+    dims = (space.STATE_DIM, 256, 128, space.ACTION_DIM)
+    model = az.ActionModel(B, dims[0], dims[-1], hidden=dims[1:-1], seed=seed)
+    om = orc.Mlp(dims, seed=seed, threads=8)
+    assert np.array_equal(model.get_params(), om.get_params())
+    colors, permitted = space.generate_roots(seed, B)
+    opt = az.NablaOptimizer.par_new(space, (colors, permitted), model, B, persistent=persistent)
+    oe = orc.Engine(n, B, threads=8, ramsey=(sizes, [1.0] * 3))
+    oe.new_begin(colors, permitted)
+    oe.new_end(opt.predictions())
+    worst = 0.0
+    for s in range(60):
+        opt.par_roll_out_episodes(tol)
+        oe.rollout_begin(*tol)
+        sv = oe.state_vecs()
+        assert np.array_equal(opt.state_vecs(), sv)
+        h = opt.predictions()
+        # rows of agents that expanded this call are fresh evaluator outputs of their state vector
+        fresh = [i for i in range(B) if oe.agent_state(i)["path"].any()]
+        if fresh:
+            worst = max(worst, float(np.max(np.abs(h[fresh] - om.forward(sv)[fresh]))))
+        oe.rollout_end(h)
+    assert worst < 2e-5, worst
+    for i in range(B):
+        assert_tree_equal(opt.get_tree(i), oe.export_tree(i), f"agent {i}")
+    loss = opt.par_update_model(5)
+    assert np.isfinite(loss)
