@@ -116,6 +116,8 @@ def lib():
     sig("azd_c21_modify_roots", C.c_int, vp, C.c_uint64, C.c_uint64, C.c_int, C.c_int, vp, vp)
     sig("azd_c21_modify_roots_dev", C.c_int, vp, C.c_uint64, C.c_uint64, C.c_int, C.c_int, vp, vp)
     sig("azd_engine_par_reset_trees_c21", C.c_int, vp, C.c_uint64, C.c_uint64, C.c_int, C.c_int)
+    sig("azd_engine_modify_roots_dev", C.c_int, vp, C.c_uint64, C.c_uint64, C.c_int, C.c_int, vp, vp)
+    sig("azd_engine_par_reset_trees_policy", C.c_int, vp, C.c_uint64, C.c_uint64, C.c_int, C.c_int)
     sig("azd_engine_par_new_begin", C.c_int, vp, vp, vp)
     sig("azd_engine_par_new_end", C.c_int, vp, vp)
     sig("azd_engine_roll_out_begin", C.c_int, vp, vp, C.c_int, C.c_uint32)

@@ -789,7 +789,10 @@ int azd_engine_par_reset_trees(azd_engine *e, const uint8_t *parents, const uint
 // device: no host round trip at the epoch boundary.
 static int c21_policy_args_ok(azd_engine *e, int kmin, int kmax) {
     if (!e || !e->initialised) return AZD_ERR_INVALID_ARGUMENT;
-    if (e->a.space != azd::SPACE_C21) return AZD_ERR_UNSUPPORTED;
+    if (e->a.space == azd::SPACE_RAMSEY) {
+        if (kmin < 1 || kmax < kmin || kmax > e->a.E || kmax * (e->a.C - 1) > azd::MAX_NODE_ACTIONS) return AZD_ERR_INVALID_ARGUMENT;
+        return AZD_OK;
+    }
     if (kmin < 1 || kmax < kmin || kmax > e->a.A || kmax > azd::MAX_NODE_ACTIONS) return AZD_ERR_INVALID_ARGUMENT;
     return AZD_OK;
 }
@@ -816,11 +819,20 @@ int azd_c21_modify_roots_dev(azd_engine *e, uint64_t seed, uint64_t epoch, int k
     AZD_HIP(hipSetDevice(e->cfg.device));
     const azd::Arenas &a = e->a;
     azd::launch_c21_modify_roots(a, seed, epoch, e->cfg.first_agent, kmin, kmax, e->d_stage_parents, e->d_stage_perm, e->stream);
-    AZD_HIP(hipMemcpyAsync(parents_out, e->d_stage_parents, (size_t)a.B * a.n, hipMemcpyDeviceToHost, e->stream));
+    AZD_HIP(hipMemcpyAsync(parents_out, e->d_stage_parents, (size_t)a.B * (a.space == azd::SPACE_RAMSEY ? a.E : a.n), hipMemcpyDeviceToHost, e->stream));
     AZD_HIP(hipMemcpyAsync(permitted_out, e->d_stage_perm, (size_t)a.B * a.KW * 8, hipMemcpyDeviceToHost, e->stream));
     AZD_HIP(hipStreamSynchronize(e->stream));
     AZD_HIP(hipGetLastError());
     return AZD_OK;
+}
+
+// space-neutral names of the two entry points above (the policy is the same for both spaces)
+int azd_engine_par_reset_trees_policy(azd_engine *e, uint64_t seed, uint64_t epoch, int kmin, int kmax) {
+    return azd_engine_par_reset_trees_c21(e, seed, epoch, kmin, kmax);
+}
+int azd_engine_modify_roots_dev(azd_engine *e, uint64_t seed, uint64_t epoch, int kmin, int kmax, uint8_t *roots_out,
+                                uint64_t *permitted_out) {
+    return azd_c21_modify_roots_dev(e, seed, epoch, kmin, kmax, roots_out, permitted_out);
 }
 
 int azd_engine_ramsey_argmin_data(azd_engine *e, azd_ramsey_argmin *out) {

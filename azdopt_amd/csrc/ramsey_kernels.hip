@@ -22,6 +22,7 @@ namespace azd {
     }
 
 #include "persistent_step.inc"
+#include "root_policy.inc"
 
 template <class SP>
 static void l_init_roots(const Arenas &a, const uint8_t *p, const uint64_t *m, hipStream_t st) {
@@ -56,6 +57,15 @@ static void l_persist(const Arenas &a, const PersistArgs *d_args, int n_calls, u
     k_argmin_log<SP><<<dim3(1), dim3(64), SP::dyn_bytes(a), st>>>(a, n_calls, n_wg, log_key, log_node);
 }
 
+template <class SP>
+static void l_modify_roots(const Arenas &a, uint64_t seed, uint64_t epoch, uint64_t first_agent, int kmin, int kmax,
+                           uint8_t *d_colors, uint64_t *d_perm, hipStream_t st) {
+    k_modify_roots<SP><<<dim3(a.B), dim3(64), SP::dyn_bytes(a), st>>>(a, seed, epoch, first_agent, kmin, kmax, d_colors, d_perm);
+}
+void ramsey_launch_modify_roots(const Arenas &a, uint64_t seed, uint64_t epoch, uint64_t first_agent, int kmin, int kmax,
+                                uint8_t *d_colors, uint64_t *d_perm, void *stream) {
+    DISPATCH_RKW(a, l_modify_roots, a, seed, epoch, first_agent, kmin, kmax, d_colors, d_perm, (hipStream_t)stream);
+}
 void ramsey_launch_init_roots(const Arenas &a, const uint8_t *d_colors, const uint64_t *d_permitted, void *stream) {
     DISPATCH_RKW(a, l_init_roots, a, d_colors, d_permitted, (hipStream_t)stream);
 }

@@ -185,10 +185,11 @@ void launch_persist(const Arenas &a, const PersistArgs *d_args, int n_calls, uns
 template <class SP>
 static void l_modify_roots(const Arenas &a, uint64_t seed, uint64_t epoch, uint64_t first_agent, int kmin, int kmax,
                            uint8_t *d_parents, uint64_t *d_perm, hipStream_t st) {
-    k_c21_modify_roots<SP::KW><<<dim3(a.B), dim3(64), SP::dyn_bytes(a), st>>>(a, seed, epoch, first_agent, kmin, kmax, d_parents, d_perm);
+    k_modify_roots<SP><<<dim3(a.B), dim3(64), SP::dyn_bytes(a), st>>>(a, seed, epoch, first_agent, kmin, kmax, d_parents, d_perm);
 }
 void launch_c21_modify_roots(const Arenas &a, uint64_t seed, uint64_t epoch, uint64_t first_agent, int kmin, int kmax,
                              uint8_t *d_parents, uint64_t *d_perm, void *stream) {
+    if (a.space == SPACE_RAMSEY) return ramsey_launch_modify_roots(a, seed, epoch, first_agent, kmin, kmax, d_parents, d_perm, stream);
     DISPATCH_KW(a, l_modify_roots, a, seed, epoch, first_agent, kmin, kmax, d_parents, d_perm, (hipStream_t)stream);
 }
 void launch_hash_predictions(float *d_out, int batch, int action_dim, uint64_t seed, uint64_t first_agent,

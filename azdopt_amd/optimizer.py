@@ -116,18 +116,22 @@ class NablaOptimizer:
         lo, hi = self.space.default_permitted_range()
         kmin = lo if kmin is None else kmin
         kmax = hi if kmax is None else kmax
-        parents = np.zeros((self.batch, self.space.n), np.uint8)
+        parents = np.zeros((self.batch, self.space.ROOT_BYTES), np.uint8)
         permitted = np.zeros((self.batch, self.space.KEY_WORDS), np.uint64)
-        fn = self._L.azd_c21_modify_roots_dev if device else self._L.azd_c21_modify_roots
+        fn = self._L.azd_engine_modify_roots_dev if device else self._L.azd_c21_modify_roots
         _lib.check(fn(self._h, seed, epoch, kmin, kmax, _lib.ptr(parents), _lib.ptr(permitted)), "azd_c21_modify_roots")
         return parents, permitted
 
-    def par_reset_trees_c21(self, seed, epoch, kmin=None, kmax=None):
-        """par_reset_trees with the c21 modify_root policy evaluated on the device (no host round trip)."""
+    def par_reset_trees_policy(self, seed, epoch, kmin=None, kmax=None):
+        """par_reset_trees with the drivers' modify_root policy (04-c21-tree.rs:172-206, 02-r44.rs:196-228)
+        evaluated on the device: no host round trip at the epoch boundary."""
         lo, hi = self.space.default_permitted_range()
         kmin = lo if kmin is None else kmin
         kmax = hi if kmax is None else kmax
-        _lib.check(self._L.azd_engine_par_reset_trees_c21(self._h, seed, epoch, kmin, kmax), "par_reset_trees_c21")
+        _lib.check(self._L.azd_engine_par_reset_trees_policy(self._h, seed, epoch, kmin, kmax), "par_reset_trees_policy")
+
+    par_reset_trees_c21 = par_reset_trees_policy
+    modify_roots = c21_modify_roots
 
     def argmin_data(self):
         """optimizer/mod.rs:361"""

@@ -262,6 +262,12 @@ int azd_c21_modify_roots(azd_engine *e, uint64_t seed, uint64_t epoch, int kmin,
 int azd_c21_modify_roots_dev(azd_engine *e, uint64_t seed, uint64_t epoch, int kmin, int kmax,
                              uint8_t *parents_out, uint64_t *permitted_out);
 int azd_engine_par_reset_trees_c21(azd_engine *e, uint64_t seed, uint64_t epoch, int kmin, int kmax);
+/* The Ramsey drivers' modify_root (02-r44.rs:196-228) is the same policy over permitted EDGES
+ * (k' of the E edges instead of k' of ACTION_DIM; a fresh root is a fresh random colouring), and
+ * the device kernel serves both spaces.  Space-neutral names of the two calls above: */
+int azd_engine_modify_roots_dev(azd_engine *e, uint64_t seed, uint64_t epoch, int kmin, int kmax,
+                                uint8_t *roots_out, uint64_t *permitted_out);
+int azd_engine_par_reset_trees_policy(azd_engine *e, uint64_t seed, uint64_t epoch, int kmin, int kmax);
 
 /* Split-phase forms of the three calls above, cut at the model call
  * (optimizer/mod.rs:72, :175-176, :348), for an external NablaModel:

@@ -86,7 +86,12 @@ def run_ramsey_parity(az, orc, n, sizes, weights, B, kmin, kmax, tol, steps, epo
         assert np.array_equal(obs[~nan].view(np.uint32), oo[~nan].view(np.uint32))
         assert np.array_equal(sv, oe.state_vecs())
         ro = oe.modify_roots(seed, epoch, first_agent, kmin, kmax)  # the drivers' modify_root policy (02-r44.rs:196-228)
-        opt.par_reset_trees(ro)
+        rg = opt.modify_roots(seed, epoch, kmin, kmax)               # the same policy on the device
+        assert np.array_equal(rg[0], ro[0]) and np.array_equal(rg[1], ro[1]), epoch
+        if epoch % 2 == 0:
+            opt.par_reset_trees_policy(seed, epoch, kmin, kmax)      # policy + reset without a host round trip
+        else:
+            opt.par_reset_trees(ro)
         oe.reset_begin(*ro)
         call += 1
         oe.reset_end(orc.hash_predictions(seed, first_agent, B, space.ACTION_DIM, call))
