@@ -358,8 +358,9 @@ struct MlpEvaluator : azd_evaluator {
         int mh = 4;
         for (int l = 0; l <= L; ++l) f->dims[l] = dims[(size_t)l];
         for (int l = 0; l < L; ++l) {
-            // the in-kernel GEMM streams float4 along K: inputs in multiples of 16, rows 16-B aligned
-            if (dims[(size_t)l] % 16 != 0 || w_off[(size_t)l] % 4 != 0) return false;
+            // the in-kernel GEMM streams float4 along K: inputs in multiples of 4, rows 16-B aligned
+            // (the asynchronous step additionally needs multiples of 16: async_plan)
+            if (dims[(size_t)l] % 4 != 0 || w_off[(size_t)l] % 4 != 0) return false;
             f->w_off[l] = w_off[(size_t)l];
             f->b_off[l] = b_off[(size_t)l];
             if (l >= 1 && dims[(size_t)l] > mh) mh = dims[(size_t)l];

@@ -57,6 +57,9 @@ void launch_async(const Arenas &a, const PersistArgs *d_args, int n_calls, unsig
 bool async_plan(const Arenas &a, const FusedEval &ev, uint32_t *dyn_stride, size_t *dyn_bytes) {
     (void)ev;
     if (a.space != SPACE_C21) return false; // the asynchronous step is built for the c21 space only
+    if (ev.kind == 3)
+        for (int l = 0; l < ev.n_layers; ++l)
+            if (ev.dims[l] % 16 != 0) return false; // its tile tasks walk K in steps of 16
     if (a.B > 65536 || a.node_cap > 65536) return false; // (agent, node) are packed 16 + 16 bits in the argmin log
     size_t stride = (dyn_lds_bytes(a.n) + 15) & ~(size_t)15;
     size_t total = stride * PERSIST_WAVES;

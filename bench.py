@@ -24,13 +24,22 @@ sys.path.insert(0, ROOT)
 
 import numpy as np  # noqa: E402
 
-N_VERTICES = 19
-AGENTS_PER_GPU = 4096
 HIDDEN = (256, 256, 256)
-TOL = ([200, 50, 50], 25)
 N_OBS_TOL = 200
 EPOCH_CALLS = 800
 SEED = 0
+# The default workload is BASELINE.json configs[1].  The Ramsey workloads (configs[3]: "Ramsey-style
+# multicolour edge space", 8192 agents per GPU = 32768 over 4 GPUs) are measured with --workload;
+# they keep the drivers' n_as_tol tables (01-r333.rs:128-130, 02-r44.rs:128-130) and use 800-call epochs
+# like c21 (the drivers run 6400 / 3200) so that the arenas stay under 20 GB.
+WORKLOADS = {
+    "c21": dict(kind="c21", n=19, agents=4096, tol=([200, 50, 50], 25), caps={}, name="c21 N=19"),
+    "r333": dict(kind="ramsey", n=16, sizes=[3, 3, 3], agents=8192,
+                 tol=([200, 200, 200, 100, 100, 100, 50, 50, 50, 25, 25, 25], 10),
+                 caps=dict(prediction_capacity=98304), name="Ramsey R(3,3,3) N=16"),
+    "r44": dict(kind="ramsey", n=17, sizes=[4, 4], agents=8192, tol=([200, 200, 100, 100, 50, 50, 25, 25], 10),
+                caps=dict(prediction_capacity=57344), name="Ramsey R(4,4) N=17"),
+}
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 
 
@@ -41,7 +50,13 @@ class _DevView:
         self.__cuda_array_interface__ = dict(shape=tuple(shape), typestr="<f4", data=(int(ptr), False), version=2)
 
 
-def algorithmic_bytes(c0, c1, state_dim):
+def make_space(az, wl):
+    if wl["kind"] == "ramsey":
+        return az.RamseySpaceNoEdgeRecolor(wl["n"], wl["sizes"])
+    return az.ROTModifyParentsOnce(wl["n"])
+
+
+def algorithmic_bytes(c0, c1, state_dim, action_dim=None, state_bytes=0):
     """Algorithmic bytes the roll-out kernel moves per expansion, SURVEY.md 8(d) with the measured
     D (select calls), deg, A, K per expansion instead of the nominal ones and this build's record
     sizes (node 32 B, arc 16 B, prediction 16 B):  selection reads + new node/arc/key writes +
@@ -56,19 +71,26 @@ def algorithmic_bytes(c0, c1, state_dim):
     cascade_bytes = d["CASCADE_NODES"] * (32 + 12 + 16)
     total = sel_bytes + write_bytes + vec_bytes + cascade_bytes
     # add_actions runs inside the persistent step too: prediction row read + new predictions written
-    total += 4 * (state_dim // 2) * d["EXPANSIONS"] + 16 * d["NEW_PREDS"]
+    total += 4 * (action_dim if action_dim else state_dim // 2) * d["EXPANSIONS"] + 16 * d["NEW_PREDS"]
+    # per-call load + store of the agent's space state (Ramsey: clique counts + neighbourhoods) and its
+    # re-read by add_actions; c21's 32-byte parent row is ignored
+    total += 3 * state_bytes * d["EXPANSIONS"]
     return total / exp, d
 
 
-def cpu_baseline(n_threads, steps):
+def cpu_baseline(n_threads, steps, wl, krange):
     """CPU restatement of the reference algorithm (oracle, OpenMP over agents like rayon's par_iter;
     CPU fp32 MLP) on a bounded sample of the same workload: the first `steps` calls."""
     from oracle import orc
-    B, n = AGENTS_PER_GPU, N_VERTICES
-    e = orc.Engine(n, B, threads=n_threads)
+    B, n, TOL = wl["agents"], wl["n"], wl["tol"]
+    if wl["kind"] == "ramsey":
+        e = orc.Engine(n, B, threads=n_threads, ramsey=(wl["sizes"], [1.0] * len(wl["sizes"])))
+        parents, permitted = orc.gen_ramsey_roots(SEED, 0, 0, B, n, len(wl["sizes"]), *krange)
+    else:
+        e = orc.Engine(n, B, threads=n_threads)
+        parents, permitted = orc.gen_roots(SEED, 0, 0, B, n, *krange)
     dims = (e.S,) + HIDDEN + (e.A,)
     mlp = orc.Mlp(dims, seed=SEED, threads=n_threads)
-    parents, permitted = orc.gen_roots(SEED, 0, 0, B, n, 5, e.A // 2)
     e.new_begin(parents, permitted)
     e.new_end(mlp.forward(e.state_vecs()))
     t0 = time.perf_counter()
@@ -91,7 +113,13 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--chunk", type=int, default=800, help="calls per host round trip (<= one epoch)")
     ap.add_argument("--async-step", action="store_true", help="asynchronous evaluator-service step (k_async) instead of the barrier step")
+    ap.add_argument("--workload", choices=sorted(WORKLOADS), default="c21")
+    ap.add_argument("--agents", type=int, default=0, help="agents per GPU (default: the workload's)")
     args = ap.parse_args()
+    wl = dict(WORKLOADS[args.workload])
+    if args.agents > 0:
+        wl["agents"] = args.agents
+    AGENTS_PER_GPU, TOL = wl["agents"], wl["tol"]
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -119,13 +147,13 @@ def main():
     from azdopt_amd.parallel import ShardPlan, allgather_training_triple, global_argmin
 
     plan = ShardPlan(world, rank, AGENTS_PER_GPU)
-    space = az.ROTModifyParentsOnce(N_VERTICES)
+    space = make_space(az, wl)
     B = plan.local_agents
     B_total = plan.total_agents
     model = az.ActionModel(B_total, space.STATE_DIM, space.ACTION_DIM, hidden=HIDDEN, seed=SEED, device=local_rank)
     roots = space.generate_roots(SEED, B, first_agent=plan.first_agent)
     opt = az.NablaOptimizer.par_new(space, roots, model, B, device=local_rank, first_agent=plan.first_agent,
-                                    async_step=args.async_step)
+                                    async_step=args.async_step, **wl["caps"])
 
     def barrier():
         if world > 1:
@@ -150,7 +178,7 @@ def main():
                 gathered = allgather_training_triple(dist, torch, views, world)
             torch.cuda.synchronize()
             losses.append(model.update_model_dev(B_total, *[g.data_ptr() for g in gathered], stream=opt.stream()))
-        opt.par_reset_trees_c21(SEED, epoch)  # modify_root policy + reset on the device
+        opt.par_reset_trees_policy(SEED, epoch)  # modify_root policy + reset on the device
         epoch += 1
 
     def run(n_calls):
@@ -186,18 +214,21 @@ def main():
     else:
         dt_max, exp_total = dt, float(exp_local)
     am = opt.argmin_data()
-    best_eval, best_cost = global_argmin(dist if world > 1 else None, torch, float(am.eval),
-                                         am.cost["lambda_1"] + len(am.cost["matching"]), local_rank, device=coll_dev)
+    cost = float(sum(am.cost["clique_counts"])) if wl["kind"] == "ramsey" else am.cost["lambda_1"] + len(am.cost["matching"])
+    best_eval, best_cost = global_argmin(dist if world > 1 else None, torch, float(am.eval), cost, local_rank, device=coll_dev)
 
     if rank == 0:
-        bytes_per_exp, d = algorithmic_bytes(c0, c1, space.STATE_DIM)
+        state_bytes = (space.C * space.E * 4 + 512) if wl["kind"] == "ramsey" else 0
+        bytes_per_exp, d = algorithmic_bytes(c0, c1, space.STATE_DIM, space.ACTION_DIM, state_bytes)
+        kw = space.KEY_WORDS
+        dims_txt = "-".join(str(x) for x in (space.STATE_DIM,) + HIDDEN + (space.ACTION_DIM,))
         launches = max(1, timing["rollout_launches"])
         avg_ms = timing["rollout_ms"] / launches
         bytes_per_launch = bytes_per_exp * exp_local / launches
         achieved = bytes_per_launch / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
         traffic = None
         tpath = os.path.join(ROOT, "profiles", "traffic.json")
-        if os.path.exists(tpath):
+        if os.path.exists(tpath) and args.workload == "c21":
             try:
                 per_call = json.load(open(tpath)).get("k_persist_hbm_bytes_per_call")
                 traffic = per_call * args.steps / launches if per_call else None  # PMC bytes per call x calls per launch
@@ -207,8 +238,9 @@ def main():
             "metric": "node_expansions_per_s", "value": exp_total / dt_max, "unit": "expansions/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * dt_max / args.steps,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "c21 N=19 tree search, %d agents/GPU, fp32 MLP 304-256-256-256-152, "
-                                   "tol [200,50,50]/25, 800 calls/epoch incl. update_model+reset_trees" % AGENTS_PER_GPU,
+            "config": {"workload": "%s tree search, %d agents/GPU, fp32 MLP %s, tol %s/%d, "
+                                   "800 calls/epoch incl. update_model+reset_trees"
+                                   % (wl["name"], AGENTS_PER_GPU, dims_txt, str(TOL[0]).replace(" ", ""), TOL[1]),
                        "agents_total": B_total, "parallelism": f"agents sharded x{world}"},
             "best_cost_found": best_cost, "best_eval": best_eval,
             "expansions": exp_total, "terminals": d["TERMINALS"], "transpositions": d["TRANSPOSITIONS"],
@@ -216,7 +248,7 @@ def main():
             "epoch_losses": losses[-3:],
             "calls_per_launch": args.steps / launches,
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "kernel": "k_async<3>" if args.async_step else "k_persist<3>",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "kernel": ("k_async<%d>" if args.async_step else "k_persist<%d>") % kw,
                          "algorithmic_bytes_per_expansion": bytes_per_exp, "avg_launch_ms": avg_ms,
                          "mlp_flop_per_launch": 2.0 * sum(a * b for a, b in zip((space.STATE_DIM,) + HIDDEN, HIDDEN + (space.ACTION_DIM,)))
                                                 * ((B + 15) // 16 * 16) * args.steps / launches,
@@ -224,7 +256,7 @@ def main():
                                  "~3 orders of magnitude apart for this workload (SURVEY.md 8d)"},
         }
         if not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(min(os.cpu_count() or 1, 64), args.cpu_steps)
+            out["cpu_baseline"] = cpu_baseline(min(os.cpu_count() or 1, 64), args.cpu_steps, wl, space.default_permitted_range())
         else:
             out["cpu_baseline"] = None
         print(json.dumps(out), flush=True)
