@@ -104,3 +104,75 @@ def test_cross_n19_reference_shape(orc, seed):
     # reference hyper-parameters scaled down: tol table [200,50,50]/25 -> [8,3,3]/2 so revisits occur quickly
     s = run_pair(orc, 19, 4, 5, 76, [8, 3, 3], 2, steps=40, epochs=1, seed=seed, n_obs_tol=4)
     assert s["FAILED"] == 0 and s["EXPANSIONS"] > 0 and s["VISITED_STEPS"] > 0
+
+
+# ---------------------------------------------------------------- Ramsey space
+def _unpack_ramsey(colors, permitted, E):
+    out = []
+    for i in range(colors.shape[0]):
+        mask = sum(int(permitted[i, w]) << (64 * w) for w in range(permitted.shape[1]))
+        out.append(([int(c) for c in colors[i]], {e for e in range(E) if mask >> e & 1}))
+    return out
+
+
+def _pack_ramsey(roots, E, kw):
+    colors = np.zeros((len(roots), E), np.uint8)
+    permitted = np.zeros((len(roots), kw), np.uint64)
+    for i, (c, m) in enumerate(roots):
+        colors[i] = c
+        for e in m:
+            permitted[i, e >> 6] |= np.uint64(1 << (e & 63))
+    return colors, permitted
+
+
+@pytest.mark.parametrize("n,sizes,weights,kmin,kmax,seed", [(6, [3, 3], [1.0, 1.0], 3, 7, 0), (7, [3, 4], [1.0, 2.0], 3, 8, 1),
+                                                              (6, [3, 3, 3], [1.0, 0.5, 2.0], 2, 6, 2), (8, [4, 5], [1.0, 1.0], 4, 9, 3)])
+def test_ramsey_restatements_agree_bit_for_bit(orc, n, sizes, weights, kmin, kmax, seed):
+    """C++ oracle (incremental counts) vs the Python restatement (recount from the definition) under the
+    same prediction stream: trees, state vectors, observations, argmin and the root policy must agree."""
+    from oracle import py_ramsey as pr
+    B, tol, tol_default, steps, epochs, n_obs_tol = 5, [6, 3, 2], 1, 45, 2, 2
+    ce = orc.Engine(n, B, threads=2, ramsey=(sizes, weights))
+    pe = pr.PyRamseyEngine(n, sizes, weights, B)
+    E = n * (n - 1) // 2
+    colors, permitted = orc.gen_ramsey_roots(seed, 0, 0, B, n, len(sizes), kmin, kmax)
+    ce.new_begin(colors, permitted)
+    pe.new_begin(_unpack_ramsey(colors, permitted, E))
+    assert np.array_equal(ce.state_vecs(), pe.vecs)
+    call = 0
+    h = orc.hash_predictions(seed, 0, B, ce.A, call)
+    ce.new_end(h)
+    pe.new_end(h)
+    assert_same_trees(ce, pe, B)
+    for epoch in range(epochs):
+        for _ in range(steps):
+            ce.rollout_begin(tol, tol_default)
+            pe.rollout_begin(tol, tol_default)
+            assert np.array_equal(ce.state_vecs(), pe.vecs)
+            call += 1
+            h = orc.hash_predictions(seed, 0, B, ce.A, call)
+            assert ce.rollout_end(h) == pe.rollout_end(h)
+            am = ce.argmin()
+            assert am["eval"].tobytes() == np.float32(pe.argmin["eval"]).tobytes()
+            assert am["parents"].tolist() == pe.argmin["state"].colors
+            assert ce.argmin_totals()[:len(sizes)].tolist() == pe.argmin["state"].totals
+        assert_same_trees(ce, pe, B)
+        for i in range(B):
+            assert ce.agent_counts(i).tolist() == pe.states[i].counts
+        oc, wc = ce.observe(n_obs_tol)
+        op, wp = pe.observe(n_obs_tol)
+        nan = np.isnan(oc)
+        assert np.array_equal(nan, np.isnan(op)) and np.array_equal(wc, wp)
+        assert np.array_equal(oc[~nan].view(np.uint32), op[~nan].view(np.uint32))
+        assert np.array_equal(ce.state_vecs(), pe.vecs)
+        rc = ce.modify_roots(seed, epoch, 0, kmin, kmax)
+        rp = pe.modify_roots(seed, epoch, 0, kmin, kmax)
+        pc = _pack_ramsey(rp, E, ce.KW)
+        assert np.array_equal(rc[0], pc[0]) and np.array_equal(rc[1], pc[1])
+        ce.reset_begin(*rc)
+        pe.reset_begin(rp)
+        call += 1
+        h = orc.hash_predictions(seed, 0, B, ce.A, call)
+        ce.reset_end(h)
+        pe.reset_end(h)
+        assert_same_trees(ce, pe, B)
