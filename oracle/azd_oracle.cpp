@@ -469,7 +469,27 @@ struct Prediction { /* tree/arc_weight.rs:11-16 */
     uint32_t edge_id = NONE;
 };
 
-using Path = std::set<uint32_t>; /* path/set.rs:6-9 ActionSet */
+/* ActionPath encodings (az-discrete-opt/src/path/{set,multiset,sequence,ord_set}.rs).  All derive Ord on their container, and the
+ * containers compare lexicographically over what they iterate, so one ordered vector serves:
+ *   ActionSet (set.rs:6-37, BTreeSet<usize>)            sorted unique elements
+ *   ActionMultiset (multiset.rs:5-42, BTreeMap<a,count>) for ActionsNeverRepeat spaces every count is 1:
+ *                                                        same identity, same order, same len as the set
+ *   ActionSequence (sequence.rs:3-36, Vec<usize>) and OrderedActionSet (ord_set.rs:3-34, also a Vec
+ *   that push_unchecked appends to)                      actions in the order taken */
+constexpr int PATH_SET = 0, PATH_SEQUENCE = 1;
+struct Path {
+    std::vector<uint32_t> v;
+    bool operator<(const Path &o) const { return v < o.v; }
+    size_t size() const { return v.size(); }
+    bool empty() const { return v.empty(); }
+    void clear() { v.clear(); }
+    void push(uint32_t a, int kind) { /* push_unchecked */
+        if (kind == PATH_SEQUENCE) v.push_back(a);
+        else v.insert(std::lower_bound(v.begin(), v.end(), a), a);
+    }
+    std::vector<uint32_t>::const_iterator begin() const { return v.begin(); } /* actions_taken */
+    std::vector<uint32_t>::const_iterator end() const { return v.end(); }
+};
 
 struct Counters {
     uint64_t v[ORC_CTR_COUNT] = {0};
@@ -649,7 +669,8 @@ struct Tree { /* tree/mod.rs:28-32 */
 
     /* tree/mod.rs:113-232.  Returns false on the reference's unreachable!() */
     bool roll_out_episodes(const Space &space, const State &root, State &state, Cost &cost, Path &path,
-                           uint32_t &state_pos, const uint32_t *tol, int ntol, uint32_t tol_default, Counters &ctr) {
+                           uint32_t &state_pos, const uint32_t *tol, int ntol, uint32_t tol_default, Counters &ctr,
+                           int path_kind = PATH_SET) {
         for (;;) {
             size_t len = path.size();
             uint32_t t = len < (size_t)ntol ? tol[len] : tol_default;
@@ -658,14 +679,14 @@ struct Tree { /* tree/mod.rs:28-32 */
             if (ch == CH_VISITED) { /* :139-151 */
                 uint32_t prediction_pos = edges[sel].prediction_pos;
                 uint32_t action_id = predictions[prediction_pos].a_id;
-                path.insert(action_id);
+                path.push(action_id, path_kind);
                 space.act(state, (int)action_id);
                 state_pos = edges[sel].node[1];
                 ctr.v[ORC_CTR_VISITED_STEPS] += 1;
             } else if (ch == CH_UNVISITED) { /* :160-218 */
                 uint32_t prediction_pos = sel;
                 uint32_t action_id = predictions[prediction_pos].a_id;
-                path.insert(action_id);
+                path.push(action_id, path_kind);
                 ctr.v[ORC_CTR_MAX_DEPTH] = std::max<uint64_t>(ctr.v[ORC_CTR_MAX_DEPTH], path.size());
                 auto f = positions.find(path);
                 if (f != positions.end()) { /* transposition, :172-179 */
@@ -729,6 +750,7 @@ struct orc_engine {
     std::vector<State> roots, states;
     std::vector<Cost> costs;
     std::vector<Path> paths;
+    int path_kind = PATH_SET;
     std::vector<uint32_t> last_positions;
     std::vector<float> state_vecs;
     std::vector<Tree> trees;
@@ -979,6 +1001,8 @@ static void engine_init(orc_engine *e, int batch, int threads) {
     e->failed.assign(batch, 0);
 }
 void orc_destroy(orc_engine *e) { delete e; }
+/* 0 = ActionSet / ActionMultiset, 1 = ActionSequence / OrderedActionSet; call before orc_new_begin */
+void orc_set_path_kind(orc_engine *e, int kind) { e->path_kind = kind; }
 const float *orc_state_vecs(orc_engine *e) { return e->state_vecs.data(); }
 
 /* optimizer/mod.rs:61-70 */
@@ -1023,7 +1047,7 @@ void orc_rollout_begin(orc_engine *e, const uint32_t *tol, int ntol, uint32_t to
 #pragma omp parallel for num_threads(e->threads) schedule(dynamic, 4)
     for (int i = 0; i < e->B; ++i) {
         bool ok = e->trees[i].roll_out_episodes(sp, e->roots[i], e->states[i], e->costs[i], e->paths[i],
-                                                e->last_positions[i], tol, ntol, tol_default, e->ctrs[i]);
+                                                e->last_positions[i], tol, ntol, tol_default, e->ctrs[i], e->path_kind);
         if (!ok) e->failed[i] = 1;
         if (!e->paths[i].empty()) sp.write_vec(e->states[i], &e->state_vecs[(size_t)i * sp.S]);
     }

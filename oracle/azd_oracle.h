@@ -82,6 +82,9 @@ void orc_ramsey_counts_new(int n, int n_colors, const int *sizes, const uint8_t 
 void orc_ramsey_act_sequence(int n, int n_colors, const int *sizes, uint8_t *colors, const int *actions,
                              int n_actions, int32_t *counts, int32_t *totals); /* mod.rs:78-164 */
 void orc_destroy(orc_engine *e);
+/* path encoding P of NablaOptimizer<Space, M, P> (az-discrete-opt/src/path/): 0 = ActionSet (= ActionMultiset on
+ * ActionsNeverRepeat spaces), 1 = ActionSequence (= OrderedActionSet).  Call before orc_new_begin. */
+void orc_set_path_kind(orc_engine *e, int kind);
 /* par_new (optimizer/mod.rs:39-118) split around the model call at :72 */
 void orc_new_begin(orc_engine *e, const uint8_t *parents, const uint64_t *permitted);
 void orc_new_end(orc_engine *e, const float *h_theta);

@@ -57,6 +57,7 @@ def lib():
     sig("orc_hash_predictions", None, C.c_uint64, C.c_uint64, C.c_int, C.c_int, C.c_uint64, vp)
     sig("orc_create", vp, C.c_int, C.c_int, C.c_int)
     sig("orc_destroy", None, vp)
+    sig("orc_set_path_kind", None, vp, C.c_int)
     sig("orc_new_begin", None, vp, vp, vp)
     sig("orc_new_end", None, vp, vp)
     sig("orc_rollout_begin", None, vp, vp, C.c_int, C.c_uint32)
@@ -170,8 +171,9 @@ class Tree:
 class Engine:
     """NablaOptimizer-shaped driver of the oracle with an injectable model."""
 
-    def __init__(self, n, batch, threads=1, ramsey=None):
-        """ramsey = (sizes, weights) selects RamseySpaceNoEdgeRecolor<B32, n, E, C>; default the c21 space"""
+    def __init__(self, n, batch, threads=1, ramsey=None, path_kind=0):
+        """ramsey = (sizes, weights) selects RamseySpaceNoEdgeRecolor<B32, n, E, C>; default the c21 space.
+        path_kind: 0 ActionSet / ActionMultiset, 1 ActionSequence / OrderedActionSet"""
         self.L = lib()
         self.n, self.B = n, batch
         if ramsey is None:
@@ -185,6 +187,7 @@ class Engine:
         self.S, self.A, self.KW = (self.L.orc_engine_state_dim(self.h), self.L.orc_engine_action_dim(self.h),
                                    self.L.orc_engine_key_words(self.h))
         self.RB = self.L.orc_engine_root_bytes(self.h)
+        self.L.orc_set_path_kind(self.h, path_kind)
 
     def __del__(self):
         if getattr(self, "h", None):

@@ -275,22 +275,33 @@ class PyTree:
 class PyEngine:
     """NablaOptimizer<ROTModifyParentsOnce<N>, M, ActionSet> with an injectable model."""
 
-    def __init__(self, n, batch):
-        self.n, self.B = n, batch
+    seq = False  # path encoding: False = ActionSet / ActionMultiset (path/set.rs, multiset.rs),
+    #              True = ActionSequence / OrderedActionSet (path/sequence.rs, ord_set.rs: a Vec in push order)
+
+    def __init__(self, n, batch, seq=False):
+        self.n, self.B, self.seq = n, batch, seq
         self.S, self.A = dims(n)
+
+    def key(self, path):
+        """the transposition key P of a path (tree/mod.rs:29 BTreeMap<P, NodeIndex>)"""
+        return tuple(path) if self.seq else frozenset(path)
+
+    def actions_taken(self, key):
+        """ActionPath::actions_taken, which is also what the derived Ord compares lexicographically"""
+        return list(key) if self.seq else sorted(key)
 
     def new_begin(self, roots):  # roots: list of (parents list, permitted set)
         self.roots = [(list(p), set(m)) for p, m in roots]
         self.states = [(list(p), set(m)) for p, m in roots]
         self.costs = [cost_eval(self.n, p) for p, _ in self.roots]
-        self.paths = [set() for _ in roots]
+        self.paths = [[] for _ in roots]
         self.posn = [0] * self.B
         self.inspected = [0] * self.B
         self.vecs = np.stack([write_vec(self.n, p, m) for p, m in self.states])
 
     def _root_tree(self, i, h_row):
         t = PyTree()
-        t.add_node(frozenset(), self.costs[i][2])
+        t.add_node(self.key([]), self.costs[i][2])
         t.add_actions(0, legal_actions(self.n, *self.roots[i]), h_row)
         return t
 
@@ -314,14 +325,14 @@ class PyEngine:
             if ch[0] == "V":
                 _, dst, pp = t.edge[ch[1]]
                 a = t.pred[pp][0]
-                path.add(a)
+                path.append(a)
                 act(parents, permitted, a)
                 self.posn[i] = dst
                 continue
             pp = ch[1]
             a = t.pred[pp][0]
-            path.add(a)
-            key = frozenset(path)
+            path.append(a)
+            key = self.key(path)
             hit = t.pos.get(key)
             if hit is not None:
                 e = t.add_edge(self.posn[i], hit, pp)
@@ -366,7 +377,7 @@ class PyEngine:
         _, i, j = best
         parents, permitted = list(self.roots[i][0]), set(self.roots[i][1])
         key = next(k for k, v in self.trees[i].pos.items() if v == j)
-        for a in sorted(key):
+        for a in self.actions_taken(key):
             act(parents, permitted, a)
         lam, mu, ev = cost_eval(self.n, parents, full=True)
         self.argmin = dict(parents=parents, permitted=permitted, lambda1=lam, matching=mu, eval=ev)
@@ -391,7 +402,7 @@ class PyEngine:
             agent = first_agent + i
             r0, r1 = key4(seed, domain, agent, 0), key4(seed, domain, agent, 1)
             parents, permitted = list(self.roots[i][0]), set(self.roots[i][1])
-            order = sorted(t.pos.items(), key=lambda kv: sorted(kv[0]))  # BTreeMap order: lexicographic
+            order = sorted(t.pos.items(), key=lambda kv: self.actions_taken(kv[0]))  # BTreeMap order: lexicographic
             c_root, c_root_star = t.node[0]["c"], t.node[0]["cs"]
             if c_root == c_root_star:
                 kcur = len(permitted)
@@ -404,7 +415,7 @@ class PyEngine:
                 thr = (c_root + F(3.0) * c_root_star) / F(4.0)
                 keep = [k for k, v in order if t.node[v]["c"] <= thr]
                 k_new = kmin + below(r1, kmax - kmin + 1)
-            for a in sorted(keep[below(r0, len(keep))]):
+            for a in self.actions_taken(keep[below(r0, len(keep))]):
                 act(parents, permitted, a)
             out.append((parents, shuffle_prefix(seed, domain, agent, self.A, k_new)))
         return out
@@ -413,7 +424,7 @@ class PyEngine:
         self.roots = [(list(p), set(m)) for p, m in roots]
         self.states = [(list(p), set(m)) for p, m in roots]
         self.costs = [cost_eval(self.n, p) for p, _ in self.roots]
-        self.paths = [set() for _ in roots]
+        self.paths = [[] for _ in roots]
         self.posn = [0] * self.B
         self.vecs = np.stack([write_vec(self.n, p, m) for p, m in self.states])
 

@@ -76,8 +76,8 @@ class RamseyTree(po.PyTree):
 class PyRamseyEngine(po.PyEngine):
     """NablaOptimizer<RamseySpaceNoEdgeRecolor<B32, N, E, C>, M, ActionSet> with an injectable model."""
 
-    def __init__(self, n, sizes, weights, batch):
-        self.n, self.B, self.sizes = n, batch, list(sizes)
+    def __init__(self, n, sizes, weights, batch, seq=False):
+        self.n, self.B, self.sizes, self.seq = n, batch, list(sizes), seq
         self.w = [F(x) for x in weights]
         self.C, self.E = len(sizes), n * (n - 1) // 2
         self.S, self.A = self.E * (2 * self.C + 1), self.E * self.C
@@ -116,14 +116,14 @@ class PyRamseyEngine(po.PyEngine):
         self.roots = [RamseyState(self.n, self.sizes, c, m) for c, m in roots]
         self.states = [r.clone() for r in self.roots]
         self.costs = [self.evaluate(r) for r in self.roots]
-        self.paths = [set() for _ in roots]
+        self.paths = [[] for _ in roots]
         self.posn = [0] * self.B
         self.inspected = [0] * self.B
         self.vecs = np.stack([self.write_vec(s) for s in self.states])
 
     def _root_tree(self, i, h_row):
         t = RamseyTree()
-        t.add_node(frozenset(), self.costs[i])
+        t.add_node(self.key([]), self.costs[i])
         t.add_actions_r(0, self.action_data(self.roots[i]), h_row, self.w)
         return t
 
@@ -145,14 +145,14 @@ class PyRamseyEngine(po.PyEngine):
             if ch[0] == "V":
                 _, dst, pp = t.edge[ch[1]]
                 a = t.pred[pp][0]
-                path.add(a)
+                path.append(a)
                 st.act(a)
                 self.posn[i] = dst
                 continue
             pp = ch[1]
             a = t.pred[pp][0]
-            path.add(a)
-            key = frozenset(path)
+            path.append(a)
+            key = self.key(path)
             hit = t.pos.get(key)
             if hit is not None:
                 t.cascade(t.add_edge(self.posn[i], hit, pp), True)
@@ -190,7 +190,7 @@ class PyRamseyEngine(po.PyEngine):
             return 0
         _, i, j = best
         st = self.roots[i].clone()
-        for a in sorted(next(k for k, v in self.trees[i].pos.items() if v == j)):
+        for a in self.actions_taken(next(k for k, v in self.trees[i].pos.items() if v == j)):
             st.act(a)
         self.argmin = dict(state=st, eval=self.evaluate(st))
         return 1
@@ -215,7 +215,7 @@ class PyRamseyEngine(po.PyEngine):
             agent = first_agent + i
             r0, r1 = po.key4(seed, domain, agent, 0), po.key4(seed, domain, agent, 1)
             st = self.roots[i].clone()
-            order = sorted(t.pos.items(), key=lambda kv: sorted(kv[0]))  # BTreeMap order
+            order = sorted(t.pos.items(), key=lambda kv: self.actions_taken(kv[0]))  # BTreeMap order
             c_root, c_root_star = t.node[0]["c"], t.node[0]["cs"]
             if c_root == c_root_star:
                 kcur = len(st.permitted)
@@ -230,7 +230,7 @@ class PyRamseyEngine(po.PyEngine):
                 thr = (c_root + F(3.0) * c_root_star) / F(4.0)
                 keep = [k for k, v in order if t.node[v]["c"] <= thr]
                 k_new = kmin + po.below(r1, kmax - kmin + 1)
-            for a in sorted(keep[po.below(r0, len(keep))]):
+            for a in self.actions_taken(keep[po.below(r0, len(keep))]):
                 st.act(a)
             out.append((list(st.colors), po.shuffle_prefix(seed, domain, agent, self.E, k_new)))
         return out
@@ -239,6 +239,6 @@ class PyRamseyEngine(po.PyEngine):
         self.roots = [RamseyState(self.n, self.sizes, c, m) for c, m in roots]
         self.states = [r.clone() for r in self.roots]
         self.costs = [self.evaluate(r) for r in self.roots]
-        self.paths = [set() for _ in roots]
+        self.paths = [[] for _ in roots]
         self.posn = [0] * self.B
         self.vecs = np.stack([self.write_vec(s) for s in self.states])

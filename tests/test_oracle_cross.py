@@ -39,9 +39,9 @@ def assert_same_trees(ce, pe, B):
                 assert np.array_equal(a.astype(np.int64), b.astype(np.int64)), (i, f)
 
 
-def run_pair(orc, n, B, kmin, kmax, tol, tol_default, steps, epochs, seed, n_obs_tol):
-    ce = orc.Engine(n, B, threads=2)
-    pe = po.PyEngine(n, B)
+def run_pair(orc, n, B, kmin, kmax, tol, tol_default, steps, epochs, seed, n_obs_tol, seq=False):
+    ce = orc.Engine(n, B, threads=2, path_kind=1 if seq else 0)
+    pe = po.PyEngine(n, B, seq=seq)
     A = ce.A
     parents, permitted = orc.gen_roots(seed, 0, 0, B, n, kmin, kmax)
     ce.new_begin(parents, permitted)
@@ -99,6 +99,18 @@ def test_cross_n8_exercises_all_branches(orc):
         assert s[k] > 0, (k, s)
 
 
+def test_cross_sequence_paths_never_transpose(orc):
+    """P = ActionSequence / OrderedActionSet: keys are the actions in the order taken, so a path can
+    only meet itself -- the search graph is a tree, and the BTreeMap order the root policy sees is
+    the lexicographic order of sequences"""
+    s = run_pair(orc, 8, 8, 2, 10, [4, 2, 2], 1, steps=60, epochs=2, seed=3, n_obs_tol=2, seq=True)
+    assert s["FAILED"] == 0 and s["TRANSPOSITIONS"] == 0
+    for k in ("EXPANSIONS", "TERMINALS", "VISITED_STEPS", "CASCADE_NODES"):
+        assert s[k] > 0, (k, s)
+    s = run_pair(orc, 5, 6, 1, 5, [3, 2], 1, steps=12, epochs=3, seed=11, n_obs_tol=1, seq=True)
+    assert s["FAILED"] == 0 and s["TRANSPOSITIONS"] == 0 and s["ROOT_EXHAUSTED"] > 0
+
+
 @pytest.mark.parametrize("seed", [0, 1])
 def test_cross_n19_reference_shape(orc, seed):
     # reference hyper-parameters scaled down: tol table [200,50,50]/25 -> [8,3,3]/2 so revisits occur quickly
@@ -125,15 +137,16 @@ def _pack_ramsey(roots, E, kw):
     return colors, permitted
 
 
+@pytest.mark.parametrize("seq", [False, True])
 @pytest.mark.parametrize("n,sizes,weights,kmin,kmax,seed", [(6, [3, 3], [1.0, 1.0], 3, 7, 0), (7, [3, 4], [1.0, 2.0], 3, 8, 1),
                                                               (6, [3, 3, 3], [1.0, 0.5, 2.0], 2, 6, 2), (8, [4, 5], [1.0, 1.0], 4, 9, 3)])
-def test_ramsey_restatements_agree_bit_for_bit(orc, n, sizes, weights, kmin, kmax, seed):
+def test_ramsey_restatements_agree_bit_for_bit(orc, n, sizes, weights, kmin, kmax, seed, seq):
     """C++ oracle (incremental counts) vs the Python restatement (recount from the definition) under the
     same prediction stream: trees, state vectors, observations, argmin and the root policy must agree."""
     from oracle import py_ramsey as pr
     B, tol, tol_default, steps, epochs, n_obs_tol = 5, [6, 3, 2], 1, 45, 2, 2
-    ce = orc.Engine(n, B, threads=2, ramsey=(sizes, weights))
-    pe = pr.PyRamseyEngine(n, sizes, weights, B)
+    ce = orc.Engine(n, B, threads=2, ramsey=(sizes, weights), path_kind=1 if seq else 0)
+    pe = pr.PyRamseyEngine(n, sizes, weights, B, seq=seq)
     E = n * (n - 1) // 2
     colors, permitted = orc.gen_ramsey_roots(seed, 0, 0, B, n, len(sizes), kmin, kmax)
     ce.new_begin(colors, permitted)
