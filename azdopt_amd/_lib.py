@@ -21,6 +21,7 @@ ENGINE_NO_PERSISTENT_STEP = 1
 ENGINE_ASYNC_STEP = 2
 SPACE_C21 = 1
 SPACE_RAMSEY = 2
+PATH_SET, PATH_SEQUENCE = 0, 1
 
 
 class AzdError(RuntimeError):
@@ -40,7 +41,8 @@ class EngineConfig(C.Structure):
     _fields_ = [("space_id", C.c_int), ("n", C.c_int), ("batch", C.c_int), ("device", C.c_int),
                 ("node_capacity", C.c_int), ("arc_capacity", C.c_int), ("prediction_capacity", C.c_int),
                 ("first_agent", C.c_uint64), ("flags", C.c_uint32),
-                ("n_colors", C.c_int), ("clique_sizes", C.c_int * 4), ("color_weights", C.c_float * 4)]
+                ("n_colors", C.c_int), ("clique_sizes", C.c_int * 4), ("color_weights", C.c_float * 4),
+                ("path_kind", C.c_int)]
 
 
 class RamseyArgmin(C.Structure):  # ArgminData<RamseyCountsNoRecolor, TotalCounts<C>>

@@ -441,6 +441,10 @@ int azd_engine_create(azd_engine **out, const azd_engine_config *cfg, azd_evalua
         azd::g_last_error = "unsupported space / n / batch";
         return AZD_ERR_INVALID_ARGUMENT;
     }
+    if (cfg->path_kind != AZD_PATH_SET && cfg->path_kind != AZD_PATH_SEQUENCE) {
+        azd::g_last_error = "unknown path encoding";
+        return AZD_ERR_INVALID_ARGUMENT;
+    }
     int st = azd::device_ok(cfg->device);
     if (st) return st;
     AZD_HIP(hipSetDevice(cfg->device));
@@ -453,6 +457,7 @@ int azd_engine_create(azd_engine **out, const azd_engine_config *cfg, azd_evalua
     a.n = cfg->n;
     a.B = cfg->batch;
     a.space = ramsey ? azd::SPACE_RAMSEY : azd::SPACE_C21;
+    a.path_kind = cfg->path_kind;
     if (ramsey) {
         a.C = cfg->n_colors;
         a.E = azd::ramsey_edges(cfg->n);
@@ -789,6 +794,10 @@ int azd_engine_par_reset_trees(azd_engine *e, const uint8_t *parents, const uint
 // device: no host round trip at the epoch boundary.
 static int c21_policy_args_ok(azd_engine *e, int kmin, int kmax) {
     if (!e || !e->initialised) return AZD_ERR_INVALID_ARGUMENT;
+    if (e->a.path_kind == azd::PATH_SEQUENCE && e->a.node_cap > 4096) {
+        azd::g_last_error = "the device root policy handles sequence-keyed trees of at most 4096 nodes";
+        return AZD_ERR_UNSUPPORTED;
+    }
     if (e->a.space == azd::SPACE_RAMSEY) {
         if (kmin < 1 || kmax < kmin || kmax > e->a.E || kmax * (e->a.C - 1) > azd::MAX_NODE_ACTIONS) return AZD_ERR_INVALID_ARGUMENT;
         return AZD_OK;
@@ -1089,7 +1098,7 @@ static bool key_less(const uint64_t *x, const uint64_t *y, int KW) {
 int azd_c21_modify_roots(azd_engine *e, uint64_t seed, uint64_t epoch, int kmin, int kmax, uint8_t *parents_out,
                          uint64_t *permitted_out) {
     if (!e || !parents_out || !permitted_out || !e->initialised) return AZD_ERR_INVALID_ARGUMENT;
-    if (e->a.space != azd::SPACE_C21) return AZD_ERR_UNSUPPORTED;
+    if (e->a.space != azd::SPACE_C21 || e->a.path_kind != azd::PATH_SET) return AZD_ERR_UNSUPPORTED;
     AZD_HIP(hipSetDevice(e->cfg.device));
     AZD_HIP(hipStreamSynchronize(e->stream));
     const azd::Arenas &a = e->a;

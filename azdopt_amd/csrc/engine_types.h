@@ -20,6 +20,7 @@ constexpr uint32_t NONE = 0xFFFFFFFFu;
 constexpr int PARENTS_STRIDE = 32; // bytes per packed parents row on the device
 constexpr int MAX_N = 24;
 constexpr int MAX_KW = 6;                   // c21 uses up to 4 key words, the Ramsey space up to 6
+constexpr int PATH_SET = 0, PATH_SEQUENCE = 1;   // = AZD_PATH_*
 constexpr int SPACE_C21 = 1, SPACE_RAMSEY = 2; // = AZD_SPACE_* of include/azdopt_amd.h
 constexpr int PRED_CHUNKS = 2;               // a node holds at most 64*PRED_CHUNKS legal actions
 constexpr int MAX_NODE_ACTIONS = 64 * PRED_CHUNKS;
@@ -131,6 +132,9 @@ struct Arenas {
     int32_t *root_counts, *cur_counts; // [B][C*E]
     int32_t *root_tot, *cur_tot;       // [B][4]
     RamseyArgminRec *argmin_r;
+    // ---- path encoding P (az-discrete-opt/src/path/): PATH_SET = ActionSet (= ActionMultiset on
+    // ActionsNeverRepeat spaces), PATH_SEQUENCE = ActionSequence (= OrderedActionSet): no transpositions
+    int path_kind;
 };
 
 // what the persistent step needs to run the evaluator inside the kernel

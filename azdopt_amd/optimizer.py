@@ -39,7 +39,7 @@ class TreeView:
 
 
 class NablaOptimizer:
-    """NablaOptimizer<Space, M, P> with P = ActionSet.
+    """NablaOptimizer<Space, M, P>; P = ActionSet (default), ActionMultiset, ActionSequence, OrderedActionSet.
 
     par_new / par_roll_out_episodes / par_update_model / par_reset_trees / argmin_data / get_trees
     keep the reference's names and meaning (optimizer/mod.rs:30-36,39,121,249,284,361).  The
@@ -47,13 +47,14 @@ class NablaOptimizer:
 
     def __init__(self, space, model, batch, device=0, first_agent=0, node_capacity=0, arc_capacity=0,
                  prediction_capacity=0, path=ActionSet, persistent=True, async_step=False):
-        if path is not ActionSet or not ActionSet.licensed_for(space):
-            raise TypeError("only ActionSet paths on ActionsNeverRepeat + ActionOrderIndependent spaces are built")
+        if not hasattr(path, "PATH_KIND") or not path.licensed_for(space):
+            raise TypeError("path encoding %r is not licensed for this space (space/axioms.rs:12-19)" % (path,))
         self.space, self.model, self.batch, self.first_agent = space, model, batch, first_agent
         self._L = _lib.lib()
         cfg = _lib.EngineConfig(space.SPACE_ID, space.n, batch, device, node_capacity, arc_capacity,
                                 prediction_capacity, first_agent,
                                 (0 if persistent else _lib.ENGINE_NO_PERSISTENT_STEP) | (_lib.ENGINE_ASYNC_STEP if async_step else 0))
+        cfg.path_kind = path.PATH_KIND
         if space.SPACE_ID == _lib.SPACE_RAMSEY:
             cfg.n_colors = space.C
             for i in range(space.C):

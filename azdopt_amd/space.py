@@ -20,10 +20,41 @@ class ActionSet:
     """Path encoding keyed by the SET of actions taken (az-discrete-opt/src/path/set.rs:6-37).
     Licensed only for spaces that are ActionsNeverRepeat + ActionOrderIndependent
     (space/axioms.rs:16-19).  On the device it is a KW x u64 bit mask per node."""
+    PATH_KIND = _lib.PATH_SET
 
     @staticmethod
     def licensed_for(space):
         return isinstance(space, ActionsNeverRepeat) and isinstance(space, ActionOrderIndependent)
+
+
+class ActionMultiset:
+    """Path encoding keyed by the multiset of actions (path/multiset.rs:5-42), licensed for
+    ActionOrderIndependent spaces (axioms.rs:14).  On a space that is also ActionsNeverRepeat every
+    multiplicity is 1, so identity, order and length coincide with ActionSet's: same device keys."""
+    PATH_KIND = _lib.PATH_SET
+
+    @staticmethod
+    def licensed_for(space):
+        return isinstance(space, ActionOrderIndependent) and isinstance(space, ActionsNeverRepeat)
+
+
+class ActionSequence:
+    """Path encoding keyed by the actions in the order taken (path/sequence.rs:3-36), licensed for
+    every space.  Distinct orders are distinct nodes: no transpositions, the search graph is a tree."""
+    PATH_KIND = _lib.PATH_SEQUENCE
+
+    @staticmethod
+    def licensed_for(space):
+        return True
+
+
+class OrderedActionSet(ActionSequence):
+    """path/ord_set.rs:3-34: despite the name a Vec that push_unchecked appends to, i.e. the same
+    key as ActionSequence; licensed for ActionsNeverRepeat spaces (axioms.rs:12)."""
+
+    @staticmethod
+    def licensed_for(space):
+        return isinstance(space, ActionsNeverRepeat)
 
 
 class ROTModifyParentsOnce(ActionsNeverRepeat, ActionOrderIndependent):

@@ -159,7 +159,18 @@ typedef struct azd_engine_config {
     int n_colors;         /* C */
     int clique_sizes[4];  /* SIZES: forbidden clique size per colour */
     float color_weights[4];
+    /* path encoding P of NablaOptimizer<Space, M, P> (az-discrete-opt/src/path/, licences in
+     * space/axioms.rs:12-19); both built spaces are ActionsNeverRepeat + ActionOrderIndependent */
+    int path_kind;        /* AZD_PATH_* */
 } azd_engine_config;
+/* ActionSet (path/set.rs): key = set of actions taken; equal sets share a node (transpositions).
+ * ActionMultiset (path/multiset.rs) coincides with it on ActionsNeverRepeat spaces: every count is 1,
+ * so identity, Ord and len are the set's. */
+#define AZD_PATH_SET 0
+/* ActionSequence (path/sequence.rs) and OrderedActionSet (path/ord_set.rs, also a Vec that
+ * push_unchecked appends to): key = actions in the order taken; a path only ever meets itself, so
+ * the search graph is a tree, and BTreeMap order = lexicographic order of the sequences. */
+#define AZD_PATH_SEQUENCE 1
 
 /* run every phase of a call as its own kernel launch instead of the CU-resident persistent step
  * (the two forms produce identical trees; the persistent step is the fast one) */
