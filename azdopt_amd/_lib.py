@@ -108,6 +108,7 @@ def lib():
     sig("azd_engine_par_update_model", C.c_int, vp, C.c_uint32, f32p)
     sig("azd_engine_par_reset_trees", C.c_int, vp, vp, vp)
     sig("azd_engine_argmin_data", C.c_int, vp, C.POINTER(Argmin))
+    sig("azd_engine_agent_counters", C.c_int, vp, vp)
     sig("azd_engine_ramsey_argmin_data", C.c_int, vp, C.POINTER(RamseyArgmin))
     sig("azd_engine_ramsey_agent_counts", C.c_int, vp, C.c_int, vp, vp)
     sig("azd_ramsey_state_dim", C.c_int, C.c_int, C.c_int)

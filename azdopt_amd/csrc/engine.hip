@@ -1000,6 +1000,14 @@ int azd_engine_counters(azd_engine *e, uint64_t *out) {
     return AZD_OK;
 }
 
+int azd_engine_agent_counters(azd_engine *e, uint64_t *out) {
+    if (!e || !out) return AZD_ERR_INVALID_ARGUMENT;
+    AZD_HIP(hipSetDevice(e->cfg.device));
+    AZD_HIP(hipStreamSynchronize(e->stream));
+    AZD_HIP(hipMemcpy(out, e->a.counters, (size_t)e->a.B * azd::NUM_COUNTERS * 8, hipMemcpyDeviceToHost));
+    return AZD_OK;
+}
+
 int azd_engine_set_timing(azd_engine *e, int enabled) {
     if (!e) return AZD_ERR_INVALID_ARGUMENT;
     e->timing = enabled != 0;

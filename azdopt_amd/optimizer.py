@@ -241,6 +241,12 @@ class NablaOptimizer:
         _lib.check(self._L.azd_engine_counters(self._h, _lib.ptr(out)), "counters")
         return {k: int(out[v]) for k, v in _lib.CTR.items()}
 
+    def agent_counters(self):
+        """per-agent counters, unreduced: dict name -> uint64 array [batch]"""
+        out = np.zeros((self.batch, _lib.CTR_COUNT), np.uint64)
+        _lib.check(self._L.azd_engine_agent_counters(self._h, _lib.ptr(out)), "agent_counters")
+        return {k: out[:, v].copy() for k, v in _lib.CTR.items()}
+
     def set_timing(self, enabled=True):
         _lib.check(self._L.azd_engine_set_timing(self._h, int(enabled)), "set_timing")
 

@@ -311,6 +311,8 @@ int azd_engine_agent_state(azd_engine *e, int agent, uint8_t *parents, uint64_t 
                            uint64_t *path, uint32_t *state_pos, double *lambda_1,
                            int *matching_size);
 int azd_engine_counters(azd_engine *e, uint64_t *out /* [AZD_CTR_COUNT] */);
+/* the same counters per agent, unreduced: out[batch][AZD_CTR_COUNT] (load-balance diagnostics) */
+int azd_engine_agent_counters(azd_engine *e, uint64_t *out);
 /* ms of GPU time spent in the tree kernels / evaluator since creation (HIP events
  * on the engine's stream; enabled by azd_engine_set_timing) */
 int azd_engine_set_timing(azd_engine *e, int enabled);

@@ -35,8 +35,16 @@ print(f"B={B} steps={steps} model={kind}: {d['EXPANSIONS'] / dt:.3e} exp/s, roll
 print("mean agent busy time per call: %.1f us; max single-agent call: %.1f us" % (tot / (B * steps) / 100, c1["TICKS_MAX_CALL"] / 100))
 for k in ("SELECT", "LOOKUP", "NEWNODE", "CASCADE"):
     print(f"  {k:8s} {100 * d['TICKS_' + k] / tot:5.1f}%")
-print("  WAIT     %5.1f%% (prediction wait incl. serving the evaluator); batches %d, rows/batch %.2f, tiles/batch %.1f" % (100 * d["TICKS_WAIT"] / tot, d["EVAL_BATCHES"], d["EVAL_ROWS"] / max(1, d["EVAL_BATCHES"]), d["EVAL_TILES"] / max(1, d["EVAL_BATCHES"])))
-print("  evaluator: %.2f us per tile task, %.1f us per batch (open->close)" % (d["TICKS_TILES"] / max(1, d["EVAL_TILES"]) / 100, d["TICKS_BATCH"] / max(1, d["EVAL_BATCHES"]) / 100))
+if async_step:
+    print("  WAIT     %5.1f%% (prediction wait incl. serving the evaluator); batches %d, rows/batch %.2f, tiles/batch %.1f" % (100 * d["TICKS_WAIT"] / tot, d["EVAL_BATCHES"], d["EVAL_ROWS"] / max(1, d["EVAL_BATCHES"]), d["EVAL_TILES"] / max(1, d["EVAL_BATCHES"])))
+    print("  evaluator: %.2f us per tile task, %.1f us per batch (open->close)" % (d["TICKS_TILES"] / max(1, d["EVAL_TILES"]) / 100, d["TICKS_BATCH"] / max(1, d["EVAL_BATCHES"]) / 100))
+if not async_step:
+    n = B * steps
+    parts = (tot / n / 100, d["TICKS_WAIT"] / n / 100, d["TICKS_TILES"] / n / 100, d["TICKS_BATCH"] / n / 100)
+    per_call = tm["rollout_ms"] / steps * 1e3
+    print("  barrier step, per call per agent: roll-out %.1f us, waiting at the barrier %.1f us, evaluator phase %.1f us, "
+          "add_actions %.1f us; kernel %.1f us per call (unaccounted %.1f: roll-out prologue/epilogue, candidate log)" % (
+              parts + (per_call, per_call - sum(parts))))
 print("  other    %5.1f%%" % (100 * (tot - sum(d['TICKS_' + k] for k in ("SELECT", "LOOKUP", "NEWNODE", "CASCADE"))) / tot))
 print("  of NEWNODE: lambda1 %.1f%%, matching %.1f%% of total" % (100 * d["TICKS_LAMBDA"] / tot, 100 * d["TICKS_MATCHING"] / tot))
 ev = d["TERMINALS"] + d["TRANSPOSITIONS"]
