@@ -55,13 +55,16 @@ void launch_async(const Arenas &a, const PersistArgs *d_args, int n_calls, unsig
 }
 // LDS plan of the asynchronous step (no evaluator buffers in LDS)
 bool async_plan(const Arenas &a, const FusedEval &ev, uint32_t *dyn_stride, size_t *dyn_bytes) {
-    (void)ev;
     if (a.space != SPACE_C21) return false; // the asynchronous step is built for the c21 space only
     if (ev.kind == 3)
         for (int l = 0; l < ev.n_layers; ++l)
             if (ev.dims[l] % 16 != 0) return false; // its tile tasks walk K in steps of 16
     if (a.B > 65536 || a.node_cap > 65536) return false; // (agent, node) are packed 16 + 16 bits in the argmin log
     size_t stride = (dyn_lds_bytes(a.n) + 15) & ~(size_t)15;
+    if (ev.kind == 3) { // a waiting agent's region holds its row's activations: [x][h0][h1] + the 16-B-per-wave skew
+        size_t rows = ((size_t)((ev.dims[0] + 3) & ~3) + 2 * (size_t)ev.max_hidden) * sizeof(float) + 16 * PERSIST_WAVES;
+        if (rows > stride) stride = (rows + 15) & ~(size_t)15;
+    }
     size_t total = stride * PERSIST_WAVES;
     const size_t static_lds = PERSIST_WAVES * (sizeof(WaveLds) + 16) + sizeof(AsyncCtl) + 256;
     if (total + static_lds > 160 * 1024) return false;

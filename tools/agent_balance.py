@@ -15,16 +15,27 @@ B, calls = 4096, 800
 space = az.ROTModifyParentsOnce(19)
 model = az.ActionModel(B, space.STATE_DIM, space.ACTION_DIM, hidden=(256, 256, 256), seed=0)
 roots = space.generate_roots(0, B)
-opt = az.NablaOptimizer.par_new(space, roots, model, B)
+async_step = len(sys.argv) > 1 and sys.argv[1] == "async"
+opt = az.NablaOptimizer.par_new(space, roots, model, B, async_step=async_step)
 tol = ([200, 50, 50], 25)
 k = np.array([sum(bin(int(w)).count("1") for w in row) for row in roots[1]])
 prev = opt.agent_counters()
-chunks = []
+chunks, waits = [], []
+opt.set_timing(True)
 for c in range(8):
     opt.par_roll_out_episodes(tol, n_calls=calls // 8)
     cur = opt.agent_counters()
     chunks.append((cur["TICKS_TOTAL"] - prev["TICKS_TOTAL"]).astype(np.float64) / 100 / (calls // 8))
+    waits.append((cur["TICKS_WAIT"] - prev["TICKS_WAIT"]).astype(np.float64) / 100 / (calls // 8))
     prev = cur
+tm = opt.timing()
+print("kernel time per call: %.1f us" % (tm["rollout_ms"] * 1e3 / calls))
+wait = np.stack(waits).mean(0)
+cyc = np.stack(chunks).mean(0) + wait
+print("wait us per call per agent: mean %.1f p99 %.1f max %.1f;  busy+wait: mean %.1f p50 %.1f p99 %.1f max %.1f" % (
+    wait.mean(), np.percentile(wait, 99), wait.max(), cyc.mean(), np.percentile(cyc, 50), np.percentile(cyc, 99), cyc.max()))
+wgc = cyc.reshape(-1, 16)
+print("busy+wait per workgroup: mean of max %.1f, max of max %.1f, min of max %.1f" % (wgc.max(1).mean(), wgc.max(1).max(), wgc.max(1).min()))
 per = np.stack(chunks)  # [8 chunks][B] mean busy us per call
 tot = per.mean(0)
 print("busy us per call, per agent over the epoch: mean %.1f  p50 %.1f  p90 %.1f  p99 %.1f  max %.1f  (max/mean %.2f)" % (
