@@ -19,6 +19,7 @@ CTR_COUNT = 32
 ACT_NONE, ACT_RELU, ACT_SIGMOID = 0, 1, 2
 ENGINE_NO_PERSISTENT_STEP = 1
 ENGINE_ASYNC_STEP = 2
+ENGINE_BARRIER_STEP = 4
 SPACE_C21 = 1
 SPACE_RAMSEY = 2
 PATH_SET, PATH_SEQUENCE = 0, 1

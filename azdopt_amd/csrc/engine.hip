@@ -536,7 +536,7 @@ int azd_engine_create(azd_engine **out, const azd_engine_config *cfg, azd_evalua
         TRY(e->alloc(&a.argmin_r, 1));
     }
     e->persist_enabled = (cfg->flags & AZD_ENGINE_NO_PERSISTENT_STEP) == 0;
-    e->barrier_step = (cfg->flags & AZD_ENGINE_ASYNC_STEP) == 0;
+    e->barrier_step = (cfg->flags & AZD_ENGINE_BARRIER_STEP) != 0;
     e->log_calls = 1024;
     {
         const size_t n_wg = (B + 15) / 16;

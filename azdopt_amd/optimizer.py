@@ -46,14 +46,14 @@ class NablaOptimizer:
     `init_states` and `modify_root` closures stay on the host and hand over packed roots."""
 
     def __init__(self, space, model, batch, device=0, first_agent=0, node_capacity=0, arc_capacity=0,
-                 prediction_capacity=0, path=ActionSet, persistent=True, async_step=False):
+                 prediction_capacity=0, path=ActionSet, persistent=True, async_step=True):
         if not hasattr(path, "PATH_KIND") or not path.licensed_for(space):
             raise TypeError("path encoding %r is not licensed for this space (space/axioms.rs:12-19)" % (path,))
         self.space, self.model, self.batch, self.first_agent = space, model, batch, first_agent
         self._L = _lib.lib()
         cfg = _lib.EngineConfig(space.SPACE_ID, space.n, batch, device, node_capacity, arc_capacity,
                                 prediction_capacity, first_agent,
-                                (0 if persistent else _lib.ENGINE_NO_PERSISTENT_STEP) | (_lib.ENGINE_ASYNC_STEP if async_step else 0))
+                                (0 if persistent else _lib.ENGINE_NO_PERSISTENT_STEP) | (0 if async_step else _lib.ENGINE_BARRIER_STEP))
         cfg.path_kind = path.PATH_KIND
         if space.SPACE_ID == _lib.SPACE_RAMSEY:
             cfg.n_colors = space.C

@@ -3,7 +3,8 @@
 
 A "step" is one NablaOptimizer::par_roll_out_episodes call over the whole agent population
 (select / expand / backup + the MLP forward + add_actions + argmin), executed by the CU-resident
-persistent kernel k_persist (16 agents per workgroup, evaluator on the matrix cores in-kernel).  Every
+persistent kernel k_async (16 agents per workgroup; an agent waiting for its prediction row serves the
+workgroup's evaluator on the matrix cores; --barrier-step selects the lock-step form k_persist).  Every
 EPOCH_CALLS steps the epoch boundary of the reference driver (04-c21-tree.rs:163-207:
 par_update_model, modify_root policy, par_reset_trees) runs INSIDE the timed region.
 
@@ -112,7 +113,7 @@ def main():
     ap.add_argument("--cpu-steps", type=int, default=200)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--chunk", type=int, default=800, help="calls per host round trip (<= one epoch)")
-    ap.add_argument("--async-step", action="store_true", help="asynchronous evaluator-service step (k_async) instead of the barrier step")
+    ap.add_argument("--barrier-step", action="store_true", help="lock-step form (k_persist) instead of the default asynchronous step (k_async)")
     ap.add_argument("--workload", choices=sorted(WORKLOADS), default="c21")
     ap.add_argument("--agents", type=int, default=0, help="agents per GPU (default: the workload's)")
     args = ap.parse_args()
@@ -153,7 +154,7 @@ def main():
     model = az.ActionModel(B_total, space.STATE_DIM, space.ACTION_DIM, hidden=HIDDEN, seed=SEED, device=local_rank)
     roots = space.generate_roots(SEED, B, first_agent=plan.first_agent)
     opt = az.NablaOptimizer.par_new(space, roots, model, B, device=local_rank, first_agent=plan.first_agent,
-                                    async_step=args.async_step, **wl["caps"])
+                                    async_step=not args.barrier_step, **wl["caps"])
 
     def barrier():
         if world > 1:
@@ -221,6 +222,7 @@ def main():
         state_bytes = (space.C * space.E * 4 + 512) if wl["kind"] == "ramsey" else 0
         bytes_per_exp, d = algorithmic_bytes(c0, c1, space.STATE_DIM, space.ACTION_DIM, state_bytes)
         kw = space.KEY_WORDS
+        use_async = wl["kind"] == "c21" and not args.barrier_step  # the engine falls back to k_persist for other spaces
         dims_txt = "-".join(str(x) for x in (space.STATE_DIM,) + HIDDEN + (space.ACTION_DIM,))
         launches = max(1, timing["rollout_launches"])
         avg_ms = timing["rollout_ms"] / launches
@@ -230,7 +232,7 @@ def main():
         tpath = os.path.join(ROOT, "profiles", "traffic.json")
         if os.path.exists(tpath) and args.workload == "c21":
             try:
-                per_call = json.load(open(tpath)).get("k_persist_hbm_bytes_per_call")
+                per_call = json.load(open(tpath)).get("k_async_hbm_bytes_per_call" if use_async else "k_persist_hbm_bytes_per_call")
                 traffic = per_call * args.steps / launches if per_call else None  # PMC bytes per call x calls per launch
             except Exception:
                 traffic = None
@@ -248,7 +250,7 @@ def main():
             "epoch_losses": losses[-3:],
             "calls_per_launch": args.steps / launches,
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "kernel": ("k_async<%d>" if args.async_step else "k_persist<%d>") % kw,
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "kernel": ("k_async<%d>" if use_async else "k_persist<%d>") % kw,
                          "algorithmic_bytes_per_expansion": bytes_per_exp, "avg_launch_ms": avg_ms,
                          "mlp_flop_per_launch": 2.0 * sum(a * b for a, b in zip((space.STATE_DIM,) + HIDDEN, HIDDEN + (space.ACTION_DIM,)))
                                                 * ((B + 15) // 16 * 16) * args.steps / launches,

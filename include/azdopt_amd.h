@@ -175,10 +175,14 @@ typedef struct azd_engine_config {
 /* run every phase of a call as its own kernel launch instead of the CU-resident persistent step
  * (the two forms produce identical trees; the persistent step is the fast one) */
 #define AZD_ENGINE_NO_PERSISTENT_STEP 1u
-/* CU-resident step with an asynchronous in-workgroup evaluator service (k_async: agents drift
- * apart, waiting agents serve MFMA tile tasks) instead of the default workgroup barrier around the
- * evaluator (k_persist).  Same results; measured on par at 4096 agents (profiles/README.md). */
+/* The CU-resident step comes in two forms with identical results.  Default: the asynchronous one
+ * (k_async: the agents of a workgroup drift apart, an agent waiting for its prediction row serves
+ * MFMA tile tasks of the workgroup's evaluator; c21 space, layer widths in multiples of 16, else the
+ * engine falls back by itself).  AZD_ENGINE_BARRIER_STEP selects the lock-step form (k_persist: a
+ * workgroup barrier around the evaluator on every call), 12 % slower at 4096 agents
+ * (profiles/README.md).  AZD_ENGINE_ASYNC_STEP is accepted for compatibility and changes nothing. */
 #define AZD_ENGINE_ASYNC_STEP 2u
+#define AZD_ENGINE_BARRIER_STEP 4u
 
 /* ArgminData<State, Cost> (az-discrete-opt/src/log.rs:1-11) for the c21 space */
 typedef struct azd_argmin {
