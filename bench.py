@@ -109,7 +109,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=1600)
-    ap.add_argument("--warmup", type=int, default=100)
+    ap.add_argument("--warmup", type=int, default=800)
     ap.add_argument("--cpu-steps", type=int, default=200)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--chunk", type=int, default=800, help="calls per host round trip (<= one epoch)")
