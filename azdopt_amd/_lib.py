@@ -98,6 +98,7 @@ def lib():
     sig("azd_evaluator_update_model", C.c_int, vp, C.c_int, vp, vp, vp, f32p)
     sig("azd_evaluator_write_predictions_dev", C.c_int, vp, C.c_int, vp, vp, vp)
     sig("azd_evaluator_update_model_dev", C.c_int, vp, C.c_int, vp, vp, vp, f32p, vp)
+    sig("azd_evaluator_set_weight_storage", C.c_int, vp, C.c_int)
     sig("azd_evaluator_num_params", C.c_int64, vp)
     sig("azd_evaluator_get_params", C.c_int, vp, vp)
     sig("azd_evaluator_set_params", C.c_int, vp, vp)

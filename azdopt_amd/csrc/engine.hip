@@ -418,6 +418,7 @@ int azd_evaluator_update_model_dev(azd_evaluator *ev, int batch, const float *d_
     AZD_HIP(hipSetDevice(ev->device));
     return ev->update_model_dev(batch, d_states, d_observations, d_action_weights, loss, (hipStream_t)stream);
 }
+int azd_evaluator_set_weight_storage(azd_evaluator *ev, int dtype) { return ev ? ev->set_weight_storage(dtype) : AZD_ERR_INVALID_ARGUMENT; }
 int64_t azd_evaluator_num_params(azd_evaluator *ev) { return ev ? ev->num_params() : 0; }
 int azd_evaluator_get_params(azd_evaluator *ev, float *out) { return ev && out ? ev->get_params(out) : AZD_ERR_INVALID_ARGUMENT; }
 int azd_evaluator_set_params(azd_evaluator *ev, const float *in) { return ev && in ? ev->set_params(in) : AZD_ERR_INVALID_ARGUMENT; }
@@ -697,7 +698,7 @@ int azd_engine_par_roll_out_episodes(azd_engine *e, const uint32_t *tol, int n_t
             e->h_pargs->ev = fe;
             AZD_HIP(hipMemcpyAsync(e->d_pargs, e->h_pargs, sizeof(azd::PersistArgs), hipMemcpyHostToDevice, e->stream));
             e->time_begin(0);
-            if (use_async) azd::launch_async(e->a, e->d_pargs, k, e->d_log_key, e->d_act_scratch, fe.params, dyn_stride, dyn_bytes, e->stream);
+            if (use_async) azd::launch_async(e->a, e->d_pargs, k, e->d_log_key, e->d_act_scratch, fe.params, fe.w16, dyn_stride, dyn_bytes, e->stream);
             else azd::launch_persist(e->a, e->d_pargs, k, e->d_log_key, e->d_log_node, dyn_stride, dyn_bytes, e->stream);
             e->time_end();
             e->ev->calls += (uint64_t)k;

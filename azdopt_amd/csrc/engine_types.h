@@ -147,6 +147,11 @@ struct FusedEval {
     int final_act;
     int max_hidden;
     long long w_off[7], b_off[7];
+    // bf16 weight storage (AZD_STORAGE_BF16): the same layout as `params` in 16-bit words; products are
+    // exact in f32, accumulation is f32 (v_mfma_f32_16x16x16_bf16), activations are rounded to bf16 as
+    // they are read; biases stay f32 in `params`
+    int bf16;
+    const uint16_t *w16;
 };
 
 struct TolTable {
@@ -169,7 +174,7 @@ void launch_argmin(const Arenas &a, int init_mode, void *stream);
 void launch_observe(const Arenas &a, uint32_t n_obs_tol, void *stream);
 bool async_plan(const Arenas &a, const FusedEval &ev, uint32_t *dyn_stride, size_t *dyn_bytes);
 void launch_async(const Arenas &a, const PersistArgs *d_args, int n_calls, unsigned long long *log_key, float *act_scratch,
-                  const float *params, uint32_t dyn_stride, size_t dyn_bytes, void *stream);
+                  const float *params, const uint16_t *w16, uint32_t dyn_stride, size_t dyn_bytes, void *stream);
 bool persist_plan(const Arenas &a, const FusedEval &ev, uint32_t *dyn_stride, size_t *dyn_bytes);
 void launch_persist(const Arenas &a, const PersistArgs *d_args, int n_calls, unsigned long long *log_key,
                     uint32_t *log_node, uint32_t dyn_stride, size_t dyn_bytes, void *stream);

@@ -42,6 +42,7 @@ struct azd_evaluator {
     virtual int64_t num_params() { return 0; }
     virtual int get_params(float *) { return AZD_ERR_UNSUPPORTED; }
     virtual int set_params(const float *) { return AZD_ERR_UNSUPPORTED; }
+    virtual int set_weight_storage(int) { return AZD_ERR_UNSUPPORTED; }
     int ensure_staging(int batch);
 };
 

@@ -17,6 +17,7 @@
 #include <vector>
 
 #include "c21_host.h"
+#include "bf16.h"
 #include "evaluator.h"
 
 namespace azd {
@@ -26,7 +27,7 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 constexpr int BM = 64, BN = 64, BK = 16;
 constexpr int LDS_LD = BM + 4; // k-major tiles: s[k][i]; +4 keeps the transposing stores off a 4-way conflict
 
-enum { EPI_NONE = 0, EPI_BIAS_ACT = 1, EPI_RELU_MASK = 2 };
+enum { EPI_NONE = 0, EPI_BIAS_ACT = 1, EPI_RELU_MASK = 2, EPI_BIAS_ACT_BF16 = 3 };
 
 // C[M,N] = epi( sum_k A(i,k) B(k,j) ).
 //   A_KC: A(i,k) = A[i*lda + k] (k contiguous) else A[k*lda + i]
@@ -133,16 +134,17 @@ __global__ __launch_bounds__(256) void k_gemm(const float *__restrict__ A, int l
     // ---- epilogue: C/D layout col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
     const int col = n0 + wn * 32 + (lane & 31);
     if (col < N) {
-        float bj = (epi == EPI_BIAS_ACT && bias) ? bias[col] : 0.f;
+        float bj = ((epi == EPI_BIAS_ACT || epi == EPI_BIAS_ACT_BF16) && bias) ? bias[col] : 0.f;
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             int row = m0 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
             if (row < M) {
                 float v = acc[r];
-                if (epi == EPI_BIAS_ACT) {
+                if (epi == EPI_BIAS_ACT || epi == EPI_BIAS_ACT_BF16) {
                     v += bj;
                     if (act == AZD_ACT_RELU) v = v > 0.f ? v : 0.f;
                     else if (act == AZD_ACT_SIGMOID) v = 1.0f / (1.0f + expf(-v));
+                    if (epi == EPI_BIAS_ACT_BF16) v = bf16_round(v); // hidden activation stored at bf16 precision
                 } else if (epi == EPI_RELU_MASK) {
                     v = aux[(size_t)row * ldaux + col] > 0.f ? v : 0.f;
                 }
@@ -150,6 +152,20 @@ __global__ __launch_bounds__(256) void k_gemm(const float *__restrict__ A, int l
             }
         }
     }
+}
+
+// ---- bf16 weight storage: w16 = RNE(params) in 16-bit words, params_q = the same values widened back
+// to f32 (what the f32 GEMM path multiplies with, so that it computes what the bf16 MFMA path computes)
+__global__ void k_quantize_bf16(const float *__restrict__ p, size_t n, uint16_t *__restrict__ w16, float *__restrict__ q) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const uint32_t b = bf16_bits(p[i]);
+    w16[i] = (uint16_t)b;
+    q[i] = __uint_as_float(b << 16);
+}
+__global__ void k_round_bf16(const float *__restrict__ in, size_t n, float *__restrict__ out) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = bf16_round(in[i]);
 }
 
 // ---- loss: weight_sum (dfdx.rs:106), then delta = dL/dz of the head and per-block loss partials
@@ -255,10 +271,15 @@ struct MlpEvaluator : azd_evaluator {
     float *d_partial = nullptr, *d_scalars = nullptr; // [0] wsum [1] loss
     float *h_scalars = nullptr;
     int cap_batch = 0;
+    bool bf16 = false;             // AZD_STORAGE_BF16
+    uint16_t *d_w16 = nullptr;     // bf16 copy of d_params (same offsets)
+    float *d_params_q = nullptr;   // the bf16 values widened to f32 (GEMM path)
+    float *d_xq = nullptr;         // input rows rounded to bf16 precision (GEMM path)
 
     ~MlpEvaluator() override {
         (void)hipSetDevice(device);
-        for (float *p : {d_params, d_grads, d_m, d_v, d_pred_train, d_delta_a, d_delta_b, d_partial, d_scalars})
+        if (d_w16) (void)hipFree(d_w16);
+        for (float *p : {d_params, d_grads, d_m, d_v, d_pred_train, d_delta_a, d_delta_b, d_partial, d_scalars, d_params_q, d_xq})
             if (p) (void)hipFree(p);
         for (float *p : d_act)
             if (p) (void)hipFree(p);
@@ -282,17 +303,31 @@ struct MlpEvaluator : azd_evaluator {
         AZD_HIP(hipMalloc(&d_pred_train, (size_t)batch * dims[(size_t)L] * 4));
         AZD_HIP(hipMalloc(&d_delta_a, (size_t)batch * maxd * 4));
         AZD_HIP(hipMalloc(&d_delta_b, (size_t)batch * maxd * 4));
+        if (d_xq) {
+            (void)hipFree(d_xq);
+            d_xq = nullptr;
+        }
+        if (bf16 || d_w16) AZD_HIP(hipMalloc(&d_xq, (size_t)batch * dims[0] * 4));
         cap_batch = batch;
         return AZD_OK;
     }
 
-    int forward(int batch, const float *d_s, float *d_p, hipStream_t st) {
+    // quant: inference with bf16-stored weights and activations (f32 accumulate); training always runs on
+    // the f32 master weights
+    int forward(int batch, const float *d_s, float *d_p, hipStream_t st, bool quant = false) {
         const float *x = d_s;
+        const float *P = quant ? d_params_q : d_params;
+        if (quant) {
+            const size_t n = (size_t)batch * dims[0];
+            k_round_bf16<<<(unsigned)((n + 255) / 256), 256, 0, st>>>(d_s, n, d_xq);
+            x = d_xq;
+        }
         for (int l = 0; l < L; ++l) {
             float *y = (l == L - 1) ? d_p : d_act[(size_t)l + 1];
             int act = (l == L - 1) ? final_act : AZD_ACT_RELU;
-            gemm<true, true>(st, x, dims[(size_t)l], d_params + w_off[(size_t)l], dims[(size_t)l], y, dims[(size_t)l + 1], batch,
-                             dims[(size_t)l + 1], dims[(size_t)l], EPI_BIAS_ACT, act, d_params + b_off[(size_t)l], nullptr, 0);
+            const int epi = (quant && l < L - 1) ? EPI_BIAS_ACT_BF16 : EPI_BIAS_ACT;
+            gemm<true, true>(st, x, dims[(size_t)l], P + w_off[(size_t)l], dims[(size_t)l], y, dims[(size_t)l + 1], batch,
+                             dims[(size_t)l + 1], dims[(size_t)l], epi, act, d_params + b_off[(size_t)l], nullptr, 0);
             x = y;
         }
         AZD_HIP(hipGetLastError());
@@ -305,7 +340,7 @@ struct MlpEvaluator : azd_evaluator {
         int s = ensure_batch(batch);
         if (s) return s;
         calls += 1;
-        return forward(batch, d_s, d_p, st);
+        return forward(batch, d_s, d_p, st, bf16);
     }
 
     // dfdx.rs:86-131
@@ -341,6 +376,7 @@ struct MlpEvaluator : azd_evaluator {
         float bc1 = 1.0f - std::pow(adam.beta1, (float)t), bc2 = 1.0f - std::pow(adam.beta2, (float)t);
         k_adam<<<(unsigned)((n_params + 255) / 256), 256, 0, st>>>(d_params, d_grads, d_m, d_v, (size_t)n_params, adam.lr, adam.beta1,
                                                                   adam.beta2, adam.eps, adam.l2, bc1, bc2);
+        if (bf16) requantize(st);
         AZD_HIP(hipGetLastError());
         AZD_HIP(hipMemcpyAsync(h_scalars, d_scalars, 2 * sizeof(float), hipMemcpyDeviceToHost, st));
         AZD_HIP(hipStreamSynchronize(st));
@@ -366,7 +402,30 @@ struct MlpEvaluator : azd_evaluator {
             if (l >= 1 && dims[(size_t)l] > mh) mh = dims[(size_t)l];
         }
         f->max_hidden = mh;
+        f->bf16 = bf16 ? 1 : 0;
+        f->w16 = d_w16;
         return true;
+    }
+    void requantize(hipStream_t st) {
+        k_quantize_bf16<<<(unsigned)((n_params + 255) / 256), 256, 0, st>>>(d_params, (size_t)n_params, d_w16, d_params_q);
+    }
+    // AZD_STORAGE_BF16: inference reads bf16 copies of the weights (refreshed after every optimiser step),
+    // the optimiser keeps f32 master weights
+    int set_weight_storage(int dtype) override {
+        AZD_HIP(hipSetDevice(device));
+        if (dtype != AZD_STORAGE_F32 && dtype != AZD_STORAGE_BF16) return AZD_ERR_INVALID_ARGUMENT;
+        AZD_HIP(hipDeviceSynchronize());
+        if (dtype == AZD_STORAGE_BF16 && !d_w16) {
+            AZD_HIP(hipMalloc(&d_w16, (size_t)n_params * 2));
+            AZD_HIP(hipMalloc(&d_params_q, (size_t)n_params * 4));
+            AZD_HIP(hipMalloc(&d_xq, (size_t)cap_batch * dims[0] * 4));
+        }
+        bf16 = dtype == AZD_STORAGE_BF16;
+        if (bf16) {
+            requantize(nullptr);
+            AZD_HIP(hipDeviceSynchronize());
+        }
+        return AZD_OK;
     }
     int64_t num_params() override { return n_params; }
     int get_params(float *out) override {
@@ -379,6 +438,10 @@ struct MlpEvaluator : azd_evaluator {
         AZD_HIP(hipSetDevice(device));
         AZD_HIP(hipDeviceSynchronize());
         AZD_HIP(hipMemcpy(d_params, in, (size_t)n_params * 4, hipMemcpyHostToDevice));
+        if (bf16) {
+            requantize(nullptr);
+            AZD_HIP(hipDeviceSynchronize());
+        }
         return AZD_OK;
     }
 };

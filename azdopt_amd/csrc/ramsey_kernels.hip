@@ -88,6 +88,7 @@ bool ramsey_persist_plan(const Arenas &a, const FusedEval &ev, uint32_t *dyn_str
     size_t stride = (per + 15) & ~(size_t)15;
     size_t total = stride * PERSIST_WAVES;
     if (ev.kind == 3) {
+        if (ev.bf16) return false; // bf16 weight storage is built into the asynchronous step only
         for (int l = 0; l < ev.n_layers; ++l)
             if (ev.dims[l] % 4 != 0) return false;
         size_t mlp = (size_t)PERSIST_WAVES * ((size_t)(ev.dims[0] + 4) + 2 * (size_t)(ev.max_hidden + 4)) * sizeof(float);

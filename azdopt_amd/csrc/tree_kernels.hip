@@ -5,6 +5,7 @@
 // ramsey_kernels.hip is the same core with the Ramsey policy.)
 #include <hip/hip_runtime.h>
 
+#include "bf16.h"
 #include "engine_types.h"
 
 namespace azd {
@@ -38,7 +39,7 @@ __global__ void k_hash_predictions(float *out, int batch, int action_dim, uint64
 #include "async_step.inc"
 template <class SP>
 static void l_async(const Arenas &a, const PersistArgs *d_args, int n_calls, unsigned long long *log_key, float *act_scratch,
-                    const float *params, uint32_t dyn_stride, size_t dyn_bytes, hipStream_t st) {
+                    const float *params, const uint16_t *w16, uint32_t dyn_stride, size_t dyn_bytes, hipStream_t st) {
     static bool attr_set = false;
     if (!attr_set) {
         (void)hipFuncSetAttribute((const void *)k_async<SP>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 16 * 1024);
@@ -46,12 +47,12 @@ static void l_async(const Arenas &a, const PersistArgs *d_args, int n_calls, uns
     }
     const int n_wg = (a.B + PERSIST_WAVES - 1) / PERSIST_WAVES;
     (void)hipMemsetAsync(log_key, 0xFF, (size_t)n_calls * sizeof(unsigned long long), st);
-    k_async<SP><<<dim3(n_wg), dim3(PERSIST_WAVES * 64), dyn_bytes, st>>>(d_args, n_calls, log_key, act_scratch, dyn_stride, params, a.state_vecs, a.h_theta);
+    k_async<SP><<<dim3(n_wg), dim3(PERSIST_WAVES * 64), dyn_bytes, st>>>(d_args, n_calls, log_key, act_scratch, dyn_stride, params, a.state_vecs, a.h_theta, w16);
     k_argmin_log1<SP><<<dim3(1), dim3(64), SP::dyn_bytes(a), st>>>(a, n_calls, log_key);
 }
 void launch_async(const Arenas &a, const PersistArgs *d_args, int n_calls, unsigned long long *log_key, float *act_scratch,
-                  const float *params, uint32_t dyn_stride, size_t dyn_bytes, void *stream) {
-    DISPATCH_KW(a, l_async, a, d_args, n_calls, log_key, act_scratch, params, dyn_stride, dyn_bytes, (hipStream_t)stream);
+                  const float *params, const uint16_t *w16, uint32_t dyn_stride, size_t dyn_bytes, void *stream) {
+    DISPATCH_KW(a, l_async, a, d_args, n_calls, log_key, act_scratch, params, w16, dyn_stride, dyn_bytes, (hipStream_t)stream);
 }
 // LDS plan of the asynchronous step (no evaluator buffers in LDS)
 bool async_plan(const Arenas &a, const FusedEval &ev, uint32_t *dyn_stride, size_t *dyn_bytes) {
@@ -172,6 +173,7 @@ bool persist_plan(const Arenas &a, const FusedEval &ev, uint32_t *dyn_stride, si
     size_t total = stride * PERSIST_WAVES;
     if (a.space == SPACE_RAMSEY) return ramsey_persist_plan(a, ev, dyn_stride, dyn_bytes);
     if (ev.kind == 3) {
+        if (ev.bf16) return false; // bf16 weight storage is built into the asynchronous step only
         for (int l = 0; l < ev.n_layers; ++l)
             if (ev.dims[l] % 4 != 0) return false; // the in-kernel MLP loads rows as float4
         size_t mlp = (size_t)PERSIST_WAVES * ((size_t)(ev.dims[0] + 4) + 2 * (size_t)(ev.max_hidden + 4)) * sizeof(float);

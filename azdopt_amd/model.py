@@ -75,7 +75,7 @@ class ActionModel(NablaModel):
     STATE -> hidden... -> ACTION, ReLU between layers, `final_act` on the head, Adam with L2."""
 
     def __init__(self, batch, state_dim, action_dim, hidden=(512, 1024, 512), final_act=_lib.ACT_SIGMOID,
-                 lr=1e-4, betas=(0.9, 0.999), eps=1e-8, l2=1e-6, seed=0, device=0):
+                 lr=1e-4, betas=(0.9, 0.999), eps=1e-8, l2=1e-6, seed=0, device=0, dtype="f32"):
         super().__init__()
         self.state_dim, self.action_dim, self.hidden = state_dim, action_dim, tuple(hidden)
         cfg = _lib.AdamConfig(lr, betas[0], betas[1], eps, l2)
@@ -83,6 +83,11 @@ class ActionModel(NablaModel):
         _lib.check(_lib.lib().azd_evaluator_create_mlp(C.byref(self._h), device, batch, state_dim, action_dim,
                                                        _lib.ptr(hid), len(hidden), final_act, C.byref(cfg), seed),
                    "azd_evaluator_create_mlp")
+        self.dtype = dtype
+        if dtype == "bf16":  # bf16 weight/activation storage for inference, f32 accumulate, f32 master weights
+            _lib.check(_lib.lib().azd_evaluator_set_weight_storage(self._h, 1), "azd_evaluator_set_weight_storage")
+        elif dtype != "f32":
+            raise ValueError("dtype must be 'f32' or 'bf16'")
 
     def num_params(self):
         return _lib.lib().azd_evaluator_num_params(self._h)

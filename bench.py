@@ -116,6 +116,8 @@ def main():
     ap.add_argument("--barrier-step", action="store_true", help="lock-step form (k_persist) instead of the default asynchronous step (k_async)")
     ap.add_argument("--workload", choices=sorted(WORKLOADS), default="c21")
     ap.add_argument("--agents", type=int, default=0, help="agents per GPU (default: the workload's)")
+    ap.add_argument("--mlp-dtype", choices=["f32", "bf16"], default="f32",
+                    help="evaluator weight/activation storage for inference (bf16 = BASELINE configs[2]; f32 accumulate either way)")
     args = ap.parse_args()
     wl = dict(WORKLOADS[args.workload])
     if args.agents > 0:
@@ -151,7 +153,8 @@ def main():
     space = make_space(az, wl)
     B = plan.local_agents
     B_total = plan.total_agents
-    model = az.ActionModel(B_total, space.STATE_DIM, space.ACTION_DIM, hidden=HIDDEN, seed=SEED, device=local_rank)
+    model = az.ActionModel(B_total, space.STATE_DIM, space.ACTION_DIM, hidden=HIDDEN, seed=SEED, device=local_rank,
+                           dtype=args.mlp_dtype)
     roots = space.generate_roots(SEED, B, first_agent=plan.first_agent)
     opt = az.NablaOptimizer.par_new(space, roots, model, B, device=local_rank, first_agent=plan.first_agent,
                                     async_step=not args.barrier_step, **wl["caps"])
@@ -239,10 +242,11 @@ def main():
         out = {
             "metric": "node_expansions_per_s", "value": exp_total / dt_max, "unit": "expansions/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * dt_max / args.steps,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "%s tree search, %d agents/GPU, fp32 MLP %s, tol %s/%d, "
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.mlp_dtype, "data": "synthetic",
+            "config": {"workload": "%s tree search, %d agents/GPU, %s MLP %s, tol %s/%d, "
                                    "800 calls/epoch incl. update_model+reset_trees"
-                                   % (wl["name"], AGENTS_PER_GPU, dims_txt, str(TOL[0]).replace(" ", ""), TOL[1]),
+                                   % (wl["name"], AGENTS_PER_GPU, "fp32" if args.mlp_dtype == "f32" else "bf16-storage", dims_txt,
+                                      str(TOL[0]).replace(" ", ""), TOL[1]),
                        "agents_total": B_total, "parallelism": f"agents sharded x{world}"},
             "best_cost_found": best_cost, "best_eval": best_eval,
             "expansions": exp_total, "terminals": d["TERMINALS"], "transpositions": d["TRANSPOSITIONS"],

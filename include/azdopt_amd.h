@@ -133,6 +133,13 @@ int azd_evaluator_update_model_dev(azd_evaluator *ev, int batch, const float *d_
                                    const float *d_observations, const float *d_action_weights,
                                    float *loss, void *stream);
 /* flat parameter vector: per layer W[out][in] then b[out] (dfdx Linear layout) */
+/* Weight storage of the MLP evaluator for INFERENCE (write_predictions and the in-kernel evaluator):
+ * AZD_STORAGE_BF16 = weights and layer inputs rounded to bf16 (RNE), products exact, f32 accumulate
+ * (v_mfma_f32_16x16x16_bf16), biases and outputs f32; the optimiser keeps f32 master weights and the bf16
+ * copy is refreshed after every step (BASELINE config C: "bf16 storage / fp32 accumulate").  Default f32. */
+#define AZD_STORAGE_F32 0
+#define AZD_STORAGE_BF16 1
+int azd_evaluator_set_weight_storage(azd_evaluator *ev, int dtype);
 int64_t azd_evaluator_num_params(azd_evaluator *ev);
 int azd_evaluator_get_params(azd_evaluator *ev, float *out);
 int azd_evaluator_set_params(azd_evaluator *ev, const float *in);

@@ -16,7 +16,8 @@ B = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
 steps = int(sys.argv[2]) if len(sys.argv) > 2 else 400
 kind = sys.argv[3] if len(sys.argv) > 3 else "mlp"
 space = az.ROTModifyParentsOnce(19)
-model = (az.ActionModel(B, space.STATE_DIM, space.ACTION_DIM, hidden=(256, 256, 256), seed=0) if kind == "mlp"
+dtype = sys.argv[5] if len(sys.argv) > 5 else "f32"
+model = (az.ActionModel(B, space.STATE_DIM, space.ACTION_DIM, hidden=(256, 256, 256), seed=0, dtype=dtype) if kind == "mlp"
          else az.HashStreamModel(space.STATE_DIM, space.ACTION_DIM, 0))
 async_step = len(sys.argv) > 4 and sys.argv[4] == "async"
 opt = az.NablaOptimizer.par_new(space, space.generate_roots(0, B), model, B, async_step=async_step)
