@@ -38,7 +38,9 @@ for k in ("SELECT", "LOOKUP", "NEWNODE", "CASCADE"):
     print(f"  {k:8s} {100 * d['TICKS_' + k] / tot:5.1f}%")
 if async_step:
     print("  WAIT     %5.1f%% (prediction wait incl. serving the evaluator); batches %d, rows/batch %.2f, tiles/batch %.1f" % (100 * d["TICKS_WAIT"] / tot, d["EVAL_BATCHES"], d["EVAL_ROWS"] / max(1, d["EVAL_BATCHES"]), d["EVAL_TILES"] / max(1, d["EVAL_BATCHES"])))
-    print("  evaluator: %.2f us per tile task, %.1f us per batch (open->close)" % (d["TICKS_TILES"] / max(1, d["EVAL_TILES"]) / 100, d["TICKS_BATCH"] / max(1, d["EVAL_BATCHES"]) / 100))
+    print("  evaluator: %.2f us per tile task (set-up %.2f, k loop %.2f, rest epilogue), %.1f us per batch (open->close)" % (
+        d["TICKS_TILES"] / max(1, d["EVAL_TILES"]) / 100, d["TICKS_TILE_SETUP"] / max(1, d["EVAL_TILES"]) / 100,
+        d["TICKS_TILE_KLOOP"] / max(1, d["EVAL_TILES"]) / 100, d["TICKS_BATCH"] / max(1, d["EVAL_BATCHES"]) / 100))
 if not async_step:
     n = B * steps
     parts = (tot / n / 100, d["TICKS_WAIT"] / n / 100, d["TICKS_TILES"] / n / 100, d["TICKS_BATCH"] / n / 100)
