@@ -364,3 +364,30 @@ def test_persistent_step_equals_launch_per_phase(az, orc):
         preds.append((o.state_vecs(), o.predictions()))
     assert np.array_equal(preds[0][0], preds[1][0])
     assert np.max(np.abs(preds[0][1] - preds[1][1])) < MLP_ATOL
+
+
+def test_reference_cost_vectors_on_the_device(az, orc):
+    """The reference's own cost vectors through the device functions (node mode and full mode):
+    star K_{1,4}: lambda_1 = 2, mu = 1; path P5: lambda_1 = 2 cos(pi/6), mu = 2 (ordered_edge.rs:198-234);
+    the 20-vertex tree of connected_bitset_graph/mod.rs:394-422: mu = 9.  lambda_1 equals the oracle's
+    bit for bit."""
+    import ctypes as C
+    import json
+    import os
+    from azdopt_amd import _lib
+    from test_oracle_golden import rooted_relabelling
+    gold = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "reference_unit_vectors.json")))
+    g = gold["tree20_matching_number"]
+    cases = [([0, 0, 0, 0, 0], 2.0, 1), ([0, 0, 1, 2, 0], 2 * np.cos(np.pi / 6), 2),
+             (rooted_relabelling(g["n_vertices"], g["edges"], last=11), None, g["matching_number"])]
+    for parents, lam_want, mu_want in cases:
+        n = len(parents)
+        p = np.array([parents], np.uint8)
+        for full in (0, 1):
+            lam, mu, ms = np.zeros(1, np.float64), np.zeros(1, np.int32), C.c_float()
+            _lib.check(az.lib().azd_debug_probe_cost(0, _lib.ptr(p), n, 1, 1, full, _lib.ptr(lam), _lib.ptr(mu), C.byref(ms)), "probe_cost")
+            assert mu[0] == mu_want
+            if lam_want is not None:
+                assert abs(lam[0] - lam_want) < 1e-6
+            fn = orc.lib().orc_lambda1_sturm if full else orc.lib().orc_lambda1_node
+            assert lam[0] == fn(_lib.ptr(p), n)

@@ -163,3 +163,37 @@ def test_seeded_generators_agree(orc):
     for i in range(3):
         assert np.array_equal(h[i], po.hash_prediction_row(5, 10 + i, 9, 152))
     assert h.min() >= 0 and h.max() < 1
+
+
+def rooted_relabelling(n, edges, last):
+    """BFS relabelling of a tree from vertex 0 so that parents[v] < v, with vertex `last` (a leaf next
+    to the root) labelled n - 1 -- the shape ROTModifyParentsOnce roots have (rooted_tree/mod.rs:14-20)"""
+    adj = {v: [] for v in range(n)}
+    for a, b in edges:
+        adj[a].append(b)
+        adj[b].append(a)
+    order, seen, q = [], {0}, [0]
+    while q:
+        v = q.pop(0)
+        if v != last:
+            order.append(v)
+        for w in sorted(adj[v]):
+            if w not in seen:
+                seen.add(w)
+                q.append(w)
+    order.append(last)
+    new = {v: i for i, v in enumerate(order)}
+    parents = [0] * n
+    for a, b in edges:
+        x, y = new[a], new[b]
+        parents[max(x, y)] = min(x, y)  # BFS: the neighbour discovered first is the parent
+    return parents
+
+
+def test_reference_tree_on_twenty_vertices_has_matching_number_nine(orc):
+    g = GOLD["tree20_matching_number"]
+    n = g["n_vertices"]
+    parents = rooted_relabelling(n, g["edges"], last=11)
+    assert parents[0] == 0 and parents[n - 1] == 0 and all(parents[v] < v for v in range(1, n))
+    assert orc.lib().orc_maximum_matching(_pv(_u8(parents)), n, None) == g["matching_number"]
+    assert po.matching_size(parents, n) == g["matching_number"]
