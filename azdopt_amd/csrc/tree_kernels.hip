@@ -84,10 +84,17 @@ __global__ void k_probe_math(const float *in, float *out, int n) {
     float x = in[2 * i], y = in[2 * i + 1];
     float d = fabsf(x - y);
     out[4 * i] = azd_sqrt(d);
-    out[4 * i + 1] = sqrtf(d);
-    out[4 * i + 2] = __fsqrt_rn(d);
     float g = x - y;
     out[4 * i + 3] = x - g;
+}
+
+// the alternatives, in a kernel of their own so that nothing is shared with azd_sqrt above
+__global__ void k_probe_sqrt_alt(const float *in, float *out, int n) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    float d = fabsf(in[2 * i] - in[2 * i + 1]);
+    out[4 * i + 1] = sqrtf(d);
+    out[4 * i + 2] = (float)sqrt((double)d);
 }
 
 // lambda_1 / matching probe: one wave per tree, `reps` repetitions (timing), result of the last one
@@ -214,6 +221,7 @@ void launch_probe_cost(const uint8_t *d_parents, int n, int count, int reps, int
 }
 void launch_probe_math(const float *d_in, float *d_out, int n, void *stream) {
     hipLaunchKernelGGL(k_probe_math, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, d_in, d_out, n);
+    hipLaunchKernelGGL(k_probe_sqrt_alt, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, d_in, d_out, n);
 }
 
 #endif // AZD_TU_ASYNC

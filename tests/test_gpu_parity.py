@@ -36,13 +36,19 @@ MAIN_CTRS = ("EXPANSIONS", "TERMINALS", "TRANSPOSITIONS", "VISITED_STEPS", "SELE
 
 
 def test_f32_primitives_bit_exact(az):
-    """sqrt(|x - y|) and x - (x - y) on the GPU equal numpy f32 bit for bit (incl. subnormals)."""
+    """sqrt(|x - y|) and x - (x - y) on the GPU equal numpy f32 bit for bit: uniform values, subnormal
+    differences, 1-ulp neighbours, exact zero, and every exponent (the selection rule's curiosity sum
+    is built from these two operations)."""
     rng = np.random.default_rng(0)
-    n = 1 << 16
+    n = 1 << 18
     x = rng.random(2 * n, dtype=np.float32)
-    x[: n // 2] *= np.float32(1e-38)  # subnormal differences
-    x[n // 2: n] = np.nextafter(x[n // 2: n], np.float32(2))  # 1-ulp neighbours
+    x[: n // 8] *= np.float32(1e-38)  # subnormal differences
+    x[n // 8: n // 4] = np.nextafter(x[n // 8: n // 4], np.float32(2))  # 1-ulp neighbours
     x[2 * 100] = x[2 * 100 + 1]  # exact zero
+    # second half: |x - y| sweeps all finite exponents with random mantissas (y = 0)
+    bits = rng.integers(0, 0x7F800000, n, dtype=np.uint32)
+    x[n::2] = bits[: n // 2].view(np.float32)
+    x[n + 1::2] = 0
     out = np.zeros(4 * n, np.float32)
     L = az.lib()
     from azdopt_amd import _lib
@@ -50,7 +56,9 @@ def test_f32_primitives_bit_exact(az):
     a, b = x[0::2], x[1::2]
     want_sqrt = np.sqrt(np.abs(a - b))
     want_sub = a - (a - b)
-    assert np.array_equal(out[0::4].view(np.uint32), want_sqrt.view(np.uint32))
+    assert np.array_equal(out[0::4].view(np.uint32), want_sqrt.view(np.uint32))  # the kernels' azd_sqrt
+    assert np.array_equal(out[1::4].view(np.uint32), want_sqrt.view(np.uint32))  # sqrtf in a kernel of its own
+    assert np.array_equal(out[2::4].view(np.uint32), want_sqrt.view(np.uint32))  # (float)sqrt((double)x)
     assert np.array_equal(out[3::4].view(np.uint32), want_sub.view(np.uint32))
 
 

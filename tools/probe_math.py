@@ -12,7 +12,7 @@ _lib.check(az.lib().azd_debug_probe_math(0, _lib.ptr(x), _lib.ptr(out), n), "pro
 a, b = x[0::2], x[1::2]
 d = np.abs(a-b)
 ws = np.sqrt(d)
-for name, off in (('azd_sqrt',0),('sqrtf',1),('__fsqrt_rn',2)):
+for name, off in (('azd_sqrt',0),('sqrtf (own kernel)',1),('f64 sqrt (own kernel)',2)):
     print(name, 'mismatches', (out[off::4].view(np.uint32) != ws.view(np.uint32)).sum())
 g = out[0::4]
 bad = np.nonzero(g.view(np.uint32) != ws.view(np.uint32))[0]
