@@ -128,8 +128,6 @@ struct azd_engine {
     // persistent (CU-resident) step
     bool persist_enabled = true;
     bool barrier_step = false;
-    float *d_act_scratch = nullptr;
-    size_t act_scratch_floats = 0;
     azd::PersistArgs *d_pargs = nullptr;
     azd::PersistArgs *h_pargs = nullptr; // pinned
     unsigned long long *d_log_key = nullptr;
@@ -587,7 +585,6 @@ int azd_engine_destroy(azd_engine *e) {
     if (e->h_status) (void)hipHostFree(e->h_status);
     if (e->h_argmin) (void)hipHostFree(e->h_argmin);
     if (e->h_pargs) (void)hipHostFree(e->h_pargs);
-    if (e->d_act_scratch) (void)hipFree(e->d_act_scratch);
     for (auto &it : e->ev_inflight) {
         (void)hipEventDestroy(it.second.first);
         (void)hipEventDestroy(it.second.second);
@@ -676,17 +673,6 @@ int azd_engine_par_roll_out_episodes(azd_engine *e, const uint32_t *tol, int n_t
     const bool use_barrier = fusable && !use_async && azd::persist_plan(e->a, fe, &dyn_stride, &dyn_bytes);
     if (use_async || use_barrier) {
         // CU-resident forms: the whole call chain, n_calls times, in one launch per <= log_calls calls
-        if (use_async && fe.kind == 3) {
-            const size_t need = (size_t)((e->a.B + 15) / 16) * 2 * 16 * (size_t)fe.max_hidden;
-            if (need > e->act_scratch_floats) {
-                AZD_HIP(hipStreamSynchronize(e->stream));
-                if (e->d_act_scratch) (void)hipFree(e->d_act_scratch);
-                e->d_act_scratch = nullptr;
-                e->act_scratch_floats = 0;
-                AZD_HIP(hipMalloc(&e->d_act_scratch, need * sizeof(float)));
-                e->act_scratch_floats = need;
-            }
-        }
         int left = n_calls;
         while (left > 0) {
             const int k = left < e->log_calls ? left : e->log_calls;
@@ -698,7 +684,7 @@ int azd_engine_par_roll_out_episodes(azd_engine *e, const uint32_t *tol, int n_t
             e->h_pargs->ev = fe;
             AZD_HIP(hipMemcpyAsync(e->d_pargs, e->h_pargs, sizeof(azd::PersistArgs), hipMemcpyHostToDevice, e->stream));
             e->time_begin(0);
-            if (use_async) azd::launch_async(e->a, e->d_pargs, k, e->d_log_key, e->d_act_scratch, fe.params, fe.w16, dyn_stride, dyn_bytes, e->stream);
+            if (use_async) azd::launch_async(e->a, e->d_pargs, k, e->d_log_key, fe.params, fe.w16, dyn_stride, dyn_bytes, e->stream);
             else azd::launch_persist(e->a, e->d_pargs, k, e->d_log_key, e->d_log_node, dyn_stride, dyn_bytes, e->stream);
             e->time_end();
             e->ev->calls += (uint64_t)k;
