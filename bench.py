@@ -179,7 +179,8 @@ def main():
             if rehearse:
                 gathered = [g.cuda() for g in allgather_training_triple(dist, torch, [v.cpu() for v in views], world)]
             else:
-                gathered = allgather_training_triple(dist, torch, views, world)
+                # the collective runs on torch-owned copies (20 MB per rank), not on the engine's own allocations
+                gathered = allgather_training_triple(dist, torch, [v.clone() for v in views], world)
             torch.cuda.synchronize()
             losses.append(model.update_model_dev(B_total, *[g.data_ptr() for g in gathered], stream=opt.stream()))
         opt.par_reset_trees_policy(SEED, epoch)  # modify_root policy + reset on the device
