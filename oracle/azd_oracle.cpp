@@ -107,6 +107,10 @@ struct State {
     uint32_t nbr[MAXC][MAXN];
     std::vector<int32_t> counts;
     int32_t total[MAXC];
+    /* Layered<L, Space> (az-discrete-opt/src/space/layered.rs, nabla/space/mod.rs:41-111): the state is
+     * Layers<State, L> (state/layers.rs), a ring of the last L states; everything above is back(), `older`
+     * holds the states before it, oldest first (at most L - 1).  Empty for a plain space. */
+    std::vector<State> older;
 };
 
 struct Cost { /* Conjecture2Dot1Cost, connected_bitset_graph/mod.rs:340-344; TotalCounts<C>, ramsey_counts/mod.rs:192-193 */
@@ -337,11 +341,18 @@ void ramsey_reassign_color(State &s, int C, int E, const int *sizes, int edge_po
 struct Space {
     int n, A, S, KW;
     int kind = SPACE_C21;
+    int layers = 1, S_inner = 0; /* Layered<L, _>: STATE_DIM = L * inner STATE_DIM (nabla/space/mod.rs:53) */
     int C = 0, E = 0, root_bytes = 0;
     int sizes[MAXC] = {0, 0, 0, 0};
     float weights[MAXC] = {0, 0, 0, 0};
     /* space.rs:56-73 act; ramsey_counts/space.rs:71-86 */
     void act(State &s, int index) const {
+        if (layers > 1) { /* Layered::act = push_op(clone of back, acted on) (nabla/space/mod.rs:65-71) */
+            State prev = s;
+            prev.older.clear();
+            s.older.push_back(std::move(prev));
+            if ((int)s.older.size() > layers - 1) s.older.erase(s.older.begin()); /* the ring drops its oldest */
+        }
         if (kind == SPACE_RAMSEY) {
             int edge_pos = index % E, new_color = index / E; /* `action`, :48-54 */
             ramsey_reassign_color(s, C, E, sizes, edge_pos, new_color);
@@ -395,7 +406,20 @@ struct Space {
         return d.empty();
     }
     /* space.rs:91-101 */
+    /* Layered::write_vec (nabla/space/mod.rs:80-96): buffer().iter() zipped with chunks_exact_mut: the states
+     * the ring holds, oldest first, each into its own chunk; chunks beyond the ring's length are NOT written
+     * (they keep whatever an earlier call left there) */
     void write_vec(const State &s, float *v) const {
+        if (layers > 1) {
+            size_t j = 0;
+            for (; j < s.older.size(); ++j) write_vec_inner(s.older[j], v + j * (size_t)S_inner);
+            write_vec_inner(s, v + j * (size_t)S_inner);
+            return;
+        }
+        write_vec_inner(s, v);
+    }
+    void write_vec_inner(const State &s, float *v) const {
+        const int S = S_inner;
         for (int i = 0; i < S; ++i) v[i] = 0.f;
         if (kind == SPACE_RAMSEY) { /* ramsey_counts/space.rs:122-153 */
             for (int i = 0; i < C * E; ++i) v[i] = (float)s.counts[i];
@@ -768,6 +792,7 @@ namespace {
 /* Packed roots.  c21: parents[n] + permitted action ids (A bits).  Ramsey: colour of every edge in
  * colex order, colors[E], + permitted edge positions (E bits); both masks are KW words per agent. */
 void unpack_state(const Space &sp, const uint8_t *parents, const uint64_t *permitted, State &s) {
+    s.older.clear(); /* Layers::new(s): a ring of one */
     std::memset(s.parents, 0, sizeof(s.parents));
     if (sp.kind == SPACE_RAMSEY) {
         std::memset(s.nbr, 0, sizeof(s.nbr));
@@ -987,6 +1012,7 @@ orc_engine *orc_create_ramsey(int n, int n_colors, const int *sizes, const float
     return e;
 }
 static void engine_init(orc_engine *e, int batch, int threads) {
+    e->space.S_inner = e->space.S;
     e->B = batch;
     e->threads = threads < 1 ? 1 : threads;
     e->roots.resize(batch);
@@ -1001,6 +1027,13 @@ static void engine_init(orc_engine *e, int batch, int threads) {
     e->failed.assign(batch, 0);
 }
 void orc_destroy(orc_engine *e) { delete e; }
+/* Layered<L, Space>: call before orc_new_begin.  state_vecs keep their contents across calls, as the
+ * optimizer's buffer does (chunks beyond the ring's length are never rewritten). */
+void orc_set_layers(orc_engine *e, int layers) {
+    e->space.layers = layers < 1 ? 1 : layers;
+    e->space.S = e->space.S_inner * e->space.layers;
+    e->state_vecs.assign((size_t)e->B * e->space.S, 0.f);
+}
 /* 0 = ActionSet / ActionMultiset, 1 = ActionSequence / OrderedActionSet; call before orc_new_begin */
 void orc_set_path_kind(orc_engine *e, int kind) { e->path_kind = kind; }
 const float *orc_state_vecs(orc_engine *e) { return e->state_vecs.data(); }

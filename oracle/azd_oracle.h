@@ -85,6 +85,9 @@ void orc_destroy(orc_engine *e);
 /* path encoding P of NablaOptimizer<Space, M, P> (az-discrete-opt/src/path/): 0 = ActionSet (= ActionMultiset on
  * ActionsNeverRepeat spaces), 1 = ActionSequence (= OrderedActionSet).  Call before orc_new_begin. */
 void orc_set_path_kind(orc_engine *e, int kind);
+/* Layered<L, Space> history wrapper (az-discrete-opt/src/space/layered.rs; nabla/space/mod.rs:41-111): the
+ * evaluator sees the last L states of the path.  Call before orc_new_begin; STATE_DIM becomes L * inner. */
+void orc_set_layers(orc_engine *e, int layers);
 /* par_new (optimizer/mod.rs:39-118) split around the model call at :72 */
 void orc_new_begin(orc_engine *e, const uint8_t *parents, const uint64_t *permitted);
 void orc_new_end(orc_engine *e, const float *h_theta);

@@ -58,6 +58,7 @@ def lib():
     sig("orc_create", vp, C.c_int, C.c_int, C.c_int)
     sig("orc_destroy", None, vp)
     sig("orc_set_path_kind", None, vp, C.c_int)
+    sig("orc_set_layers", None, vp, C.c_int)
     sig("orc_new_begin", None, vp, vp, vp)
     sig("orc_new_end", None, vp, vp)
     sig("orc_rollout_begin", None, vp, vp, C.c_int, C.c_uint32)
@@ -171,7 +172,7 @@ class Tree:
 class Engine:
     """NablaOptimizer-shaped driver of the oracle with an injectable model."""
 
-    def __init__(self, n, batch, threads=1, ramsey=None, path_kind=0):
+    def __init__(self, n, batch, threads=1, ramsey=None, path_kind=0, layers=1):
         """ramsey = (sizes, weights) selects RamseySpaceNoEdgeRecolor<B32, n, E, C>; default the c21 space.
         path_kind: 0 ActionSet / ActionMultiset, 1 ActionSequence / OrderedActionSet"""
         self.L = lib()
@@ -188,6 +189,9 @@ class Engine:
                                    self.L.orc_engine_key_words(self.h))
         self.RB = self.L.orc_engine_root_bytes(self.h)
         self.L.orc_set_path_kind(self.h, path_kind)
+        if layers > 1:  # Layered<L, Space>
+            self.L.orc_set_layers(self.h, layers)
+            self.S = self.L.orc_engine_state_dim(self.h)
 
     def __del__(self):
         if getattr(self, "h", None):

@@ -278,9 +278,39 @@ class PyEngine:
     seq = False  # path encoding: False = ActionSet / ActionMultiset (path/set.rs, multiset.rs),
     #              True = ActionSequence / OrderedActionSet (path/sequence.rs, ord_set.rs: a Vec in push order)
 
-    def __init__(self, n, batch, seq=False):
+    def __init__(self, n, batch, seq=False, layers=1):
         self.n, self.B, self.seq = n, batch, seq
         self.S, self.A = dims(n)
+        self.set_layers(layers)
+
+    # ---- Layered<L, Space> (space/layered.rs, nabla/space/mod.rs:41-111): the state is a ring of the last
+    # L states (state/layers.rs); self.states[i] is back(), self.older[i] the states before it (oldest
+    # first, at most L - 1).  The state-vector rows persist across calls; only the chunks of states the
+    # ring holds are rewritten.
+    def set_layers(self, layers):
+        self.L = layers
+        self.S_inner = self.S
+        self.S = self.S_inner * layers
+        self.vecs = np.zeros((self.B, self.S), F)
+        self.older = [[] for _ in range(self.B)]
+
+    def clone_state(self, st):
+        return (list(st[0]), set(st[1]))
+
+    def inner_vec(self, st):
+        return write_vec(self.n, *st)
+
+    def push_layer(self, i):
+        """Layered::act pushes a clone of back() before acting on it (nabla/space/mod.rs:65-71)"""
+        if self.L > 1:
+            self.older[i].append(self.clone_state(self.states[i]))
+            if len(self.older[i]) > self.L - 1:
+                self.older[i].pop(0)
+
+    def write_row(self, i, back, older):
+        k = self.S_inner
+        for j, st in enumerate(list(older) + [back]):
+            self.vecs[i, j * k:(j + 1) * k] = self.inner_vec(st)
 
     def key(self, path):
         """the transposition key P of a path (tree/mod.rs:29 BTreeMap<P, NodeIndex>)"""
@@ -297,7 +327,9 @@ class PyEngine:
         self.paths = [[] for _ in roots]
         self.posn = [0] * self.B
         self.inspected = [0] * self.B
-        self.vecs = np.stack([write_vec(self.n, p, m) for p, m in self.states])
+        self.older = [[] for _ in range(self.B)]  # Layers::new: a ring of one
+        for i in range(self.B):
+            self.write_row(i, self.states[i], [])
 
     def _root_tree(self, i, h_row):
         t = PyTree()
@@ -326,6 +358,7 @@ class PyEngine:
                 _, dst, pp = t.edge[ch[1]]
                 a = t.pred[pp][0]
                 path.append(a)
+                self.push_layer(i)
                 act(parents, permitted, a)
                 self.posn[i] = dst
                 continue
@@ -338,6 +371,7 @@ class PyEngine:
                 e = t.add_edge(self.posn[i], hit, pp)
                 t.cascade(e, True)
             else:
+                self.push_layer(i)
                 act(parents, permitted, a)
                 self.costs[i] = cost_eval(n, parents)
                 v = t.add_node(key, self.costs[i][2])
@@ -349,6 +383,7 @@ class PyEngine:
             parents[:] = self.roots[i][0]
             permitted.clear()
             permitted.update(self.roots[i][1])
+            self.older[i].clear()  # state.clone_from(root): the root's ring holds one state
             path.clear()
             self.posn[i] = 0
 
@@ -356,7 +391,7 @@ class PyEngine:
         for i in range(self.B):
             self._step(i, tol, tol_default)
             if self.paths[i]:
-                self.vecs[i] = write_vec(self.n, *self.states[i])
+                self.write_row(i, self.states[i], self.older[i])
 
     def rollout_end(self, h):
         for i in range(self.B):
@@ -387,7 +422,7 @@ class PyEngine:
         obs = np.zeros((self.B, self.A), F)
         w = np.zeros((self.B, self.A), F)
         for i, t in enumerate(self.trees):
-            self.vecs[i] = write_vec(self.n, *self.roots[i])
+            self.write_row(i, self.roots[i], [])
             for e in reversed(t.out[0]):
                 _, k, pp = t.edge[e]
                 if (not t.active(k)) or t.node[k]["n"] >= n_obs_tol:
@@ -426,7 +461,9 @@ class PyEngine:
         self.costs = [cost_eval(self.n, p) for p, _ in self.roots]
         self.paths = [[] for _ in roots]
         self.posn = [0] * self.B
-        self.vecs = np.stack([write_vec(self.n, p, m) for p, m in self.states])
+        self.older = [[] for _ in range(self.B)]  # Layers::new: a ring of one
+        for i in range(self.B):
+            self.write_row(i, self.states[i], [])
 
     def reset_end(self, h):
         self.trees = [self._root_tree(i, h[i]) for i in range(self.B)]

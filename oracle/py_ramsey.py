@@ -76,11 +76,18 @@ class RamseyTree(po.PyTree):
 class PyRamseyEngine(po.PyEngine):
     """NablaOptimizer<RamseySpaceNoEdgeRecolor<B32, N, E, C>, M, ActionSet> with an injectable model."""
 
-    def __init__(self, n, sizes, weights, batch, seq=False):
+    def __init__(self, n, sizes, weights, batch, seq=False, layers=1):
         self.n, self.B, self.sizes, self.seq = n, batch, list(sizes), seq
         self.w = [F(x) for x in weights]
         self.C, self.E = len(sizes), n * (n - 1) // 2
         self.S, self.A = self.E * (2 * self.C + 1), self.E * self.C
+        self.set_layers(layers)
+
+    def clone_state(self, st):
+        return st.clone()
+
+    def inner_vec(self, st):
+        return self.write_vec(st)
 
     # ---- space
     def evaluate(self, st):  # space.rs:159-165
@@ -101,7 +108,7 @@ class PyRamseyEngine(po.PyEngine):
         return out
 
     def write_vec(self, st):  # space.rs:122-153
-        v = np.zeros(self.S, F)
+        v = np.zeros(self.S_inner, F)
         C, E = self.C, self.E
         for c in range(C):
             for e in range(E):
@@ -119,7 +126,9 @@ class PyRamseyEngine(po.PyEngine):
         self.paths = [[] for _ in roots]
         self.posn = [0] * self.B
         self.inspected = [0] * self.B
-        self.vecs = np.stack([self.write_vec(s) for s in self.states])
+        self.older = [[] for _ in range(self.B)]
+        for i in range(self.B):
+            self.write_row(i, self.states[i], [])
 
     def _root_tree(self, i, h_row):
         t = RamseyTree()
@@ -146,6 +155,7 @@ class PyRamseyEngine(po.PyEngine):
                 _, dst, pp = t.edge[ch[1]]
                 a = t.pred[pp][0]
                 path.append(a)
+                self.push_layer(i)
                 st.act(a)
                 self.posn[i] = dst
                 continue
@@ -157,6 +167,7 @@ class PyRamseyEngine(po.PyEngine):
             if hit is not None:
                 t.cascade(t.add_edge(self.posn[i], hit, pp), True)
             else:
+                self.push_layer(i)
                 st.act(a)
                 self.costs[i] = self.evaluate(st)
                 v = t.add_node(key, self.costs[i])
@@ -166,6 +177,7 @@ class PyRamseyEngine(po.PyEngine):
                     return
                 t.cascade(e, False)
             st = self.states[i] = self.roots[i].clone()
+            self.older[i].clear()
             path.clear()
             self.posn[i] = 0
 
@@ -173,7 +185,7 @@ class PyRamseyEngine(po.PyEngine):
         for i in range(self.B):
             self._step(i, tol, tol_default)
             if self.paths[i]:
-                self.vecs[i] = self.write_vec(self.states[i])
+                self.write_row(i, self.states[i], self.older[i])
 
     def rollout_end(self, h):
         for i in range(self.B):
@@ -199,7 +211,7 @@ class PyRamseyEngine(po.PyEngine):
         obs = np.zeros((self.B, self.A), F)
         w = np.zeros((self.B, self.A), F)
         for i, t in enumerate(self.trees):
-            self.vecs[i] = self.write_vec(self.roots[i])
+            self.write_row(i, self.roots[i], [])
             for e in reversed(t.out[0]):
                 _, k, pp = t.edge[e]
                 if (not t.active(k)) or t.node[k]["n"] >= n_obs_tol:
@@ -241,4 +253,6 @@ class PyRamseyEngine(po.PyEngine):
         self.costs = [self.evaluate(r) for r in self.roots]
         self.paths = [[] for _ in roots]
         self.posn = [0] * self.B
-        self.vecs = np.stack([self.write_vec(s) for s in self.states])
+        self.older = [[] for _ in range(self.B)]
+        for i in range(self.B):
+            self.write_row(i, self.states[i], [])

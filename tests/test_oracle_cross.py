@@ -39,9 +39,9 @@ def assert_same_trees(ce, pe, B):
                 assert np.array_equal(a.astype(np.int64), b.astype(np.int64)), (i, f)
 
 
-def run_pair(orc, n, B, kmin, kmax, tol, tol_default, steps, epochs, seed, n_obs_tol, seq=False):
-    ce = orc.Engine(n, B, threads=2, path_kind=1 if seq else 0)
-    pe = po.PyEngine(n, B, seq=seq)
+def run_pair(orc, n, B, kmin, kmax, tol, tol_default, steps, epochs, seed, n_obs_tol, seq=False, layers=1):
+    ce = orc.Engine(n, B, threads=2, path_kind=1 if seq else 0, layers=layers)
+    pe = po.PyEngine(n, B, seq=seq, layers=layers)
     A = ce.A
     parents, permitted = orc.gen_roots(seed, 0, 0, B, n, kmin, kmax)
     ce.new_begin(parents, permitted)
@@ -111,6 +111,16 @@ def test_cross_sequence_paths_never_transpose(orc):
     assert s["FAILED"] == 0 and s["TRANSPOSITIONS"] == 0 and s["ROOT_EXHAUSTED"] > 0
 
 
+@pytest.mark.parametrize("layers", [2, 3])
+def test_cross_layered_history(orc, layers):
+    """Layered<L, Space>: the state vector carries the last L states of the path (chunks of states the ring
+    does not hold keep their earlier contents); the search itself is unchanged"""
+    plain = run_pair(orc, 8, 8, 2, 10, [4, 2, 2], 1, steps=60, epochs=2, seed=3, n_obs_tol=2)
+    s = run_pair(orc, 8, 8, 2, 10, [4, 2, 2], 1, steps=60, epochs=2, seed=3, n_obs_tol=2, layers=layers)
+    for k in ("EXPANSIONS", "TERMINALS", "TRANSPOSITIONS", "VISITED_STEPS", "CASCADE_NODES"):
+        assert s[k] == plain[k] > 0, k
+
+
 @pytest.mark.parametrize("seed", [0, 1])
 def test_cross_n19_reference_shape(orc, seed):
     # reference hyper-parameters scaled down: tol table [200,50,50]/25 -> [8,3,3]/2 so revisits occur quickly
@@ -145,8 +155,9 @@ def test_ramsey_restatements_agree_bit_for_bit(orc, n, sizes, weights, kmin, kma
     same prediction stream: trees, state vectors, observations, argmin and the root policy must agree."""
     from oracle import py_ramsey as pr
     B, tol, tol_default, steps, epochs, n_obs_tol = 5, [6, 3, 2], 1, 45, 2, 2
-    ce = orc.Engine(n, B, threads=2, ramsey=(sizes, weights), path_kind=1 if seq else 0)
-    pe = pr.PyRamseyEngine(n, sizes, weights, B, seq=seq)
+    layers = 2 if (seq and len(sizes) == 2) else 1  # also exercise Layered<2, _> on two of the cases
+    ce = orc.Engine(n, B, threads=2, ramsey=(sizes, weights), path_kind=1 if seq else 0, layers=layers)
+    pe = pr.PyRamseyEngine(n, sizes, weights, B, seq=seq, layers=layers)
     E = n * (n - 1) // 2
     colors, permitted = orc.gen_ramsey_roots(seed, 0, 0, B, n, len(sizes), kmin, kmax)
     ce.new_begin(colors, permitted)
