@@ -7,6 +7,7 @@ from ._lib import ACT_NONE, ACT_RELU, ACT_SIGMOID, AzdError, build, lib  # noqa:
 from .model import ActionModel, HashStreamModel, NablaModel, TrivialModel  # noqa: F401
 from .optimizer import ArgminData, NablaOptimizer, RamseyArgminData, TreeView  # noqa: F401
 from . import sinks  # noqa: F401
+from .space import Layered  # noqa: F401
 from .space import ActionMultiset, ActionOrderIndependent, ActionSequence, ActionSet, OrderedActionSet, ActionsNeverRepeat, RamseySpaceNoEdgeRecolor, ROTModifyParentsOnce  # noqa: F401
 
 

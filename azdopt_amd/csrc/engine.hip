@@ -440,6 +440,10 @@ int azd_engine_create(azd_engine **out, const azd_engine_config *cfg, azd_evalua
         azd::g_last_error = "unsupported space / n / batch";
         return AZD_ERR_INVALID_ARGUMENT;
     }
+    if (cfg->layers < 0 || cfg->layers > 8) {
+        azd::g_last_error = "layers must be 0/1 (plain space) or 2..8";
+        return AZD_ERR_INVALID_ARGUMENT;
+    }
     if (cfg->path_kind != AZD_PATH_SET && cfg->path_kind != AZD_PATH_SEQUENCE) {
         azd::g_last_error = "unknown path encoding";
         return AZD_ERR_INVALID_ARGUMENT;
@@ -457,6 +461,7 @@ int azd_engine_create(azd_engine **out, const azd_engine_config *cfg, azd_evalua
     a.B = cfg->batch;
     a.space = ramsey ? azd::SPACE_RAMSEY : azd::SPACE_C21;
     a.path_kind = cfg->path_kind;
+    a.layers = cfg->layers > 1 ? cfg->layers : 1;
     if (ramsey) {
         a.C = cfg->n_colors;
         a.E = azd::ramsey_edges(cfg->n);
@@ -473,6 +478,8 @@ int azd_engine_create(azd_engine **out, const azd_engine_config *cfg, azd_evalua
         a.KW = azd::c21_key_words(cfg->n);
         a.eval_slope = azd::c21_eval_slope(cfg->n);
     }
+    a.S_inner = a.S;
+    a.S = a.S_inner * a.layers; // Layered<L, Space>::STATE_DIM (nabla/space/mod.rs:53)
     if (ev && (ev->state_dim != a.S || ev->action_dim != a.A)) {
         delete e;
         azd::g_last_error = "evaluator dimensions do not match the space";
@@ -525,6 +532,7 @@ int azd_engine_create(azd_engine **out, const azd_engine_config *cfg, azd_evalua
     TRY(e->alloc(&a.weights, B * a.A));
     TRY(e->alloc(&a.argmin, 1));
     TRY(e->alloc(&a.status, 1));
+    if (a.layers > 1) TRY(e->alloc(&a.cur_seq, B * azd::MAX_NODE_ACTIONS));
     if (ramsey) {
         TRY(e->alloc(&a.root_nbr, B * 128));
         TRY(e->alloc(&a.cur_nbr, B * 128));
@@ -565,6 +573,7 @@ int azd_engine_create(azd_engine **out, const azd_engine_config *cfg, azd_evalua
     if (he == hipSuccess) he = hipMemsetAsync(a.argmin, 0, sizeof(azd::ArgminRec), e->stream);
     if (he == hipSuccess) he = hipMemsetAsync(a.flags, 0, B * 4, e->stream);
     if (he == hipSuccess) he = hipMemsetAsync(a.h_theta, 0, B * a.A * 4, e->stream);
+    if (he == hipSuccess) he = hipMemsetAsync(a.state_vecs, 0, B * a.S * 4, e->stream); // vec![0.; ..] (optimizer/mod.rs:65)
     if (he == hipSuccess) he = hipMemsetAsync(a.weights, 0, B * a.A * 4, e->stream);
     if (he == hipSuccess) he = hipStreamSynchronize(e->stream);
     if (he != hipSuccess) {

@@ -135,6 +135,11 @@ struct Arenas {
     // ---- path encoding P (az-discrete-opt/src/path/): PATH_SET = ActionSet (= ActionMultiset on
     // ActionsNeverRepeat spaces), PATH_SEQUENCE = ActionSequence (= OrderedActionSet): no transpositions
     int path_kind;
+    // ---- Layered<L, Space> (az-discrete-opt/src/space/layered.rs; nabla/space/mod.rs:41-111): the evaluator
+    // sees the last `layers` states of the current path; S = layers * S_inner.  The ring of states is not
+    // stored: a state of the path is the root plus a prefix of the path's actions, kept in order in cur_seq.
+    int layers, S_inner;
+    uint16_t *cur_seq; // [B][MAX_NODE_ACTIONS] actions of the current path in the order taken (layers > 1)
 };
 
 // what the persistent step needs to run the evaluator inside the kernel

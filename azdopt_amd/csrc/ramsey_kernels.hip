@@ -47,10 +47,12 @@ static void l_observe(const Arenas &a, uint32_t tol, hipStream_t st) {
 template <class SP>
 static void l_persist(const Arenas &a, const PersistArgs *d_args, int n_calls, unsigned long long *log_key,
                       uint32_t *log_node, uint32_t dyn_stride, size_t dyn_bytes, hipStream_t st) {
-    static bool attr_set = false;
-    if (!attr_set) {
-        (void)hipFuncSetAttribute((const void *)k_persist<SP>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 24 * 1024);
-        attr_set = true;
+    // dynamic LDS beyond the default limit needs the attribute; ask for what this launch uses (a request
+    // that cannot fit beside the kernel's static LDS fails and the error would stick to the stream)
+    static size_t attr_bytes = 0;
+    if (dyn_bytes > attr_bytes) {
+        if (hipFuncSetAttribute((const void *)k_persist<SP>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn_bytes) == hipSuccess) attr_bytes = dyn_bytes;
+        else (void)hipGetLastError();
     }
     const int n_wg = (a.B + PERSIST_WAVES - 1) / PERSIST_WAVES;
     k_persist<SP><<<dim3(n_wg), dim3(PERSIST_WAVES * 64), dyn_bytes, st>>>(d_args, n_calls, log_key, log_node, dyn_stride);
@@ -95,7 +97,7 @@ bool ramsey_persist_plan(const Arenas &a, const FusedEval &ev, uint32_t *dyn_str
         if (mlp > total) total = mlp;
     }
     const size_t static_lds = PERSIST_WAVES * (sizeof(RamseyLds) + 16) + 256;
-    if (total + static_lds > 160 * 1024 - 24 * 1024) return false;
+    if (total + static_lds > 160 * 1024) return false;
     *dyn_stride = (uint32_t)stride;
     *dyn_bytes = total;
     return true;

@@ -40,10 +40,12 @@ __global__ void k_hash_predictions(float *out, int batch, int action_dim, uint64
 template <class SP>
 static void l_async(const Arenas &a, const PersistArgs *d_args, int n_calls, unsigned long long *log_key,
                     const float *params, const uint16_t *w16, uint32_t dyn_stride, size_t dyn_bytes, hipStream_t st) {
-    static bool attr_set = false;
-    if (!attr_set) {
-        (void)hipFuncSetAttribute((const void *)k_async<SP>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 16 * 1024);
-        attr_set = true;
+    // dynamic LDS beyond the default limit needs the attribute; ask for what this launch uses (a request
+    // that cannot fit beside the kernel's static LDS fails and the error would stick to the stream)
+    static size_t attr_bytes = 0;
+    if (dyn_bytes > attr_bytes) {
+        if (hipFuncSetAttribute((const void *)k_async<SP>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn_bytes) == hipSuccess) attr_bytes = dyn_bytes;
+        else (void)hipGetLastError();
     }
     const int n_wg = (a.B + PERSIST_WAVES - 1) / PERSIST_WAVES;
     (void)hipMemsetAsync(log_key, 0xFF, (size_t)n_calls * sizeof(unsigned long long), st);
@@ -165,10 +167,12 @@ void launch_observe(const Arenas &a, uint32_t n_obs_tol, void *stream) {
 template <class SP>
 static void l_persist(const Arenas &a, const PersistArgs *d_args, int n_calls, unsigned long long *log_key,
                       uint32_t *log_node, uint32_t dyn_stride, size_t dyn_bytes, hipStream_t st) {
-    static bool attr_set = false;
-    if (!attr_set) {
-        (void)hipFuncSetAttribute((const void *)k_persist<SP>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 16 * 1024);
-        attr_set = true;
+    // dynamic LDS beyond the default limit needs the attribute; ask for what this launch uses (a request
+    // that cannot fit beside the kernel's static LDS fails and the error would stick to the stream)
+    static size_t attr_bytes = 0;
+    if (dyn_bytes > attr_bytes) {
+        if (hipFuncSetAttribute((const void *)k_persist<SP>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn_bytes) == hipSuccess) attr_bytes = dyn_bytes;
+        else (void)hipGetLastError();
     }
     const int n_wg = (a.B + PERSIST_WAVES - 1) / PERSIST_WAVES;
     k_persist<SP><<<dim3(n_wg), dim3(PERSIST_WAVES * 64), dyn_bytes, st>>>(d_args, n_calls, log_key, log_node, dyn_stride);

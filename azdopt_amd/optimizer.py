@@ -55,6 +55,7 @@ class NablaOptimizer:
                                 prediction_capacity, first_agent,
                                 (0 if persistent else _lib.ENGINE_NO_PERSISTENT_STEP) | (0 if async_step else _lib.ENGINE_BARRIER_STEP))
         cfg.path_kind = path.PATH_KIND
+        cfg.layers = getattr(space, "layers", 1)
         if space.SPACE_ID == _lib.SPACE_RAMSEY:
             cfg.n_colors = space.C
             for i in range(space.C):

@@ -146,3 +146,21 @@ class RamseySpaceNoEdgeRecolor(ActionsNeverRepeat, ActionOrderIndependent):
     def action(self, index):
         """(edge position, new colour) of action `index` (space.rs:48-54)"""
         return index % self.E, index // self.E
+
+
+class Layered:
+    """Layered<LAYERS, Space> (az-discrete-opt/src/space/layered.rs:3-20; trait impl nabla/space/mod.rs:41-111):
+    the evaluator sees the last `layers` states of the path.  STATE_DIM = layers * inner STATE_DIM; every other
+    method is the inner space's on the newest state; the axioms are inherited (layered.rs:12-19)."""
+
+    def __init__(self, space, layers):
+        if not 2 <= int(layers) <= 8:
+            raise ValueError("layers must be 2..8")
+        self.space, self.layers = space, int(layers)
+        self.STATE_DIM = space.STATE_DIM * self.layers  # nabla/space/mod.rs:53
+        # marker axioms follow the inner space
+        self.__class__ = type("Layered", (Layered,) + tuple(b for b in (ActionsNeverRepeat, ActionOrderIndependent)
+                                                            if isinstance(space, b)), {})
+
+    def __getattr__(self, name):  # ACTION_DIM, KEY_WORDS, n, SPACE_ID, generate_roots, ...
+        return getattr(self.space, name)

@@ -169,6 +169,12 @@ typedef struct azd_engine_config {
     /* path encoding P of NablaOptimizer<Space, M, P> (az-discrete-opt/src/path/, licences in
      * space/axioms.rs:12-19); both built spaces are ActionsNeverRepeat + ActionOrderIndependent */
     int path_kind;        /* AZD_PATH_* */
+    /* Layered<L, Space> history wrapper (az-discrete-opt/src/space/layered.rs; nabla/space/mod.rs:41-111):
+     * 0 or 1 = plain space; L = 2..8: STATE_DIM becomes L * inner STATE_DIM and a state vector carries the
+     * last L states of the agent's path, oldest first; chunks of states the ring does not hold yet keep
+     * their earlier contents, as in the reference.  A root installed by par_new / par_reset_trees is a ring
+     * of one (Layers::new). */
+    int layers;
 } azd_engine_config;
 /* ActionSet (path/set.rs): key = set of actions taken; equal sets share a node (transpositions).
  * ActionMultiset (path/multiset.rs) coincides with it on ActionsNeverRepeat spaces: every count is 1,

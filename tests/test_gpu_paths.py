@@ -95,3 +95,61 @@ def test_unlicensed_path_is_refused(az):
         az.NablaOptimizer(NoAxioms(), None, 4, path=az.ActionSet)
     with pytest.raises(TypeError):
         az.NablaOptimizer(NoAxioms(), None, 4, path=az.OrderedActionSet)
+
+
+@pytest.mark.parametrize("layers,persistent,async_step", [(2, True, True), (3, True, False), (3, False, False)])
+def test_c21_layered_history(az, orc, layers, persistent, async_step):
+    """Layered<L, Space> (space/layered.rs): state vectors carry the last L states of the path, everything
+    else is the plain search; all three step forms against the oracle"""
+    n, B, seed, kmin, kmax = 8, 40, 3, 2, 10
+    tol = ([4, 2, 2], 1)
+    space = az.Layered(az.ROTModifyParentsOnce(n), layers)
+    model = az.HashStreamModel(space.STATE_DIM, space.ACTION_DIM, seed, 0)
+    roots = space.generate_roots(seed, B, kmin=kmin, kmax=kmax)
+    opt = az.NablaOptimizer.par_new(space, roots, model, B, persistent=persistent, async_step=async_step)
+    oe = orc.Engine(n, B, threads=8, layers=layers)
+    assert oe.S == space.STATE_DIM
+    oe.new_begin(*roots)
+    call = 0
+    oe.new_end(orc.hash_predictions(seed, 0, B, space.ACTION_DIM, call))
+    assert np.array_equal(opt.state_vecs(), oe.state_vecs())
+    for epoch in range(2):
+        for s in range(0, 60, 6):
+            opt.par_roll_out_episodes(tol, n_calls=6)
+            for _ in range(6):
+                oe.rollout_begin(*tol)
+                call += 1
+                oe.rollout_end(orc.hash_predictions(seed, 0, B, space.ACTION_DIM, call))
+            assert np.array_equal(opt.state_vecs(), oe.state_vecs()), (epoch, s)
+            for i in range(B):
+                assert_tree_equal(opt.get_tree(i), oe.export_tree(i), f"epoch {epoch} step {s} agent {i}")
+        sv, obs, w = opt.observe(2)
+        oo, ow = oe.observe(2)
+        assert np.array_equal(sv, oe.state_vecs()) and np.array_equal(obs, oo) and np.array_equal(w, ow)
+        ro = oe.modify_roots(seed, epoch, 0, kmin, kmax)
+        opt.par_reset_trees_policy(seed, epoch, kmin, kmax)
+        oe.reset_begin(*ro)
+        call += 1
+        oe.reset_end(orc.hash_predictions(seed, 0, B, space.ACTION_DIM, call))
+        assert np.array_equal(opt.state_vecs(), oe.state_vecs())
+
+
+def test_ramsey_layered_history_with_mlp(az, orc):
+    """Layered<2, Ramsey> with the MLP evaluator (input = two stacked state vectors)"""
+    n, sizes, B, seed = 8, [3, 4], 24, 7
+    tol = ([6, 3, 2], 1)
+    space = az.Layered(az.RamseySpaceNoEdgeRecolor(n, sizes, [1.0, 2.0]), 2)
+    model = az.ActionModel(B, space.STATE_DIM, space.ACTION_DIM, hidden=(64, 32), seed=seed)
+    roots = space.generate_roots(seed, B, kmin=3, kmax=8)
+    opt = az.NablaOptimizer.par_new(space, roots, model, B)
+    oe = orc.Engine(n, B, threads=8, ramsey=(sizes, [1.0, 2.0]), layers=2)
+    oe.new_begin(*roots)
+    oe.new_end(opt.predictions())
+    for s in range(50):
+        opt.par_roll_out_episodes(tol)
+        oe.rollout_begin(*tol)
+        assert np.array_equal(opt.state_vecs(), oe.state_vecs()), s
+        oe.rollout_end(opt.predictions())
+    for i in range(B):
+        assert_tree_equal(opt.get_tree(i), oe.export_tree(i), f"agent {i}")
+    assert np.isfinite(opt.par_update_model(2))
