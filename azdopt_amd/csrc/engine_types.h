@@ -199,6 +199,9 @@ void ramsey_launch_argmin(const Arenas &a, int init_mode, void *stream);
 void ramsey_launch_observe(const Arenas &a, uint32_t n_obs_tol, void *stream);
 void ramsey_launch_modify_roots(const Arenas &a, uint64_t seed, uint64_t epoch, uint64_t first_agent, int kmin, int kmax,
                                 uint8_t *d_colors, uint64_t *d_perm, void *stream);
+bool ramsey_async_plan(const Arenas &a, const FusedEval &ev, uint32_t *dyn_stride, size_t *dyn_bytes);
+void ramsey_launch_async(const Arenas &a, const PersistArgs *d_args, int n_calls, unsigned long long *log_key,
+                         const float *params, const uint16_t *w16, uint32_t dyn_stride, size_t dyn_bytes, void *stream);
 bool ramsey_persist_plan(const Arenas &a, const FusedEval &ev, uint32_t *dyn_stride, size_t *dyn_bytes);
 void ramsey_launch_persist(const Arenas &a, const PersistArgs *d_args, int n_calls, unsigned long long *log_key,
                            uint32_t *log_node, uint32_t dyn_stride, size_t dyn_bytes, void *stream);

@@ -1,0 +1,63 @@
+// ramsey_async_kernels.hip -- the asynchronous CU-resident step (async_step.inc) for the Ramsey space, in
+// its own translation unit like the c21 one (async_kernels.hip): co-compiled with k_persist the shared
+// device functions are register-allocated worse.
+#define AZD_TU_ASYNC 1
+#include <hip/hip_runtime.h>
+
+#include "bf16.h"
+#include "engine_types.h"
+
+namespace azd {
+
+#include "tree_core.inc"
+#include "space_ramsey.inc"
+#include "persistent_step.inc"
+#include "async_step.inc"
+
+#define DISPATCH_RKW(A, FN, ...)                                  \
+    switch ((A).KW) {                                             \
+    case 1: FN<RamseySpace<1>>(__VA_ARGS__); break;               \
+    case 2: FN<RamseySpace<2>>(__VA_ARGS__); break;               \
+    case 3: FN<RamseySpace<3>>(__VA_ARGS__); break;               \
+    case 4: FN<RamseySpace<4>>(__VA_ARGS__); break;               \
+    case 5: FN<RamseySpace<5>>(__VA_ARGS__); break;               \
+    default: FN<RamseySpace<6>>(__VA_ARGS__); break;              \
+    }
+
+template <class SP>
+static void l_async(const Arenas &a, const PersistArgs *d_args, int n_calls, unsigned long long *log_key,
+                    const float *params, const uint16_t *w16, uint32_t dyn_stride, size_t dyn_bytes, hipStream_t st) {
+    static size_t attr_bytes = 0;
+    if (dyn_bytes > attr_bytes) {
+        if (hipFuncSetAttribute((const void *)k_async<SP>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn_bytes) == hipSuccess) attr_bytes = dyn_bytes;
+        else (void)hipGetLastError();
+    }
+    const int n_wg = (a.B + PERSIST_WAVES - 1) / PERSIST_WAVES;
+    (void)hipMemsetAsync(log_key, 0xFF, (size_t)n_calls * sizeof(unsigned long long), st);
+    k_async<SP><<<dim3(n_wg), dim3(PERSIST_WAVES * 64), dyn_bytes, st>>>(d_args, n_calls, log_key, dyn_stride, params, a.state_vecs, a.h_theta, w16);
+    k_argmin_log1<SP><<<dim3(1), dim3(64), SP::dyn_bytes(a), st>>>(a, n_calls, log_key);
+}
+void ramsey_launch_async(const Arenas &a, const PersistArgs *d_args, int n_calls, unsigned long long *log_key,
+                         const float *params, const uint16_t *w16, uint32_t dyn_stride, size_t dyn_bytes, void *stream) {
+    DISPATCH_RKW(a, l_async, a, d_args, n_calls, log_key, params, w16, dyn_stride, dyn_bytes, (hipStream_t)stream);
+}
+// LDS plan of the asynchronous step: the per-wave region holds the search scratch + the clique counts
+// during a call, and the row's activations [x][h0][h1] while the agent waits
+bool ramsey_async_plan(const Arenas &a, const FusedEval &ev, uint32_t *dyn_stride, size_t *dyn_bytes) {
+    if (a.B > 65536 || a.node_cap > 65536) return false; // (agent, node) are packed 16 + 16 bits in the argmin log
+    size_t stride = (RamseySpace<1>::dyn_bytes(a) + 15) & ~(size_t)15;
+    if (ev.kind == 3) {
+        for (int l = 0; l < ev.n_layers; ++l)
+            if (ev.dims[l] % (l == 0 ? 4 : 16) != 0) return false;
+        size_t rows = ((size_t)((ev.dims[0] + 15) & ~15) + 2 * (size_t)ev.max_hidden) * sizeof(float) + 16 * PERSIST_WAVES;
+        if (rows > stride) stride = (rows + 15) & ~(size_t)15;
+    }
+    const size_t total = stride * PERSIST_WAVES;
+    const size_t static_lds = PERSIST_WAVES * (sizeof(RamseyLds) + 16) + sizeof(AsyncCtl) + 256;
+    if (total + static_lds > 160 * 1024) return false;
+    *dyn_stride = (uint32_t)stride;
+    *dyn_bytes = total;
+    return true;
+}
+
+} // namespace azd

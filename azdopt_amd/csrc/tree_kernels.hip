@@ -54,18 +54,19 @@ static void l_async(const Arenas &a, const PersistArgs *d_args, int n_calls, uns
 }
 void launch_async(const Arenas &a, const PersistArgs *d_args, int n_calls, unsigned long long *log_key,
                   const float *params, const uint16_t *w16, uint32_t dyn_stride, size_t dyn_bytes, void *stream) {
+    if (a.space == SPACE_RAMSEY) return ramsey_launch_async(a, d_args, n_calls, log_key, params, w16, dyn_stride, dyn_bytes, stream);
     DISPATCH_KW(a, l_async, a, d_args, n_calls, log_key, params, w16, dyn_stride, dyn_bytes, (hipStream_t)stream);
 }
 // LDS plan of the asynchronous step (no evaluator buffers in LDS)
 bool async_plan(const Arenas &a, const FusedEval &ev, uint32_t *dyn_stride, size_t *dyn_bytes) {
-    if (a.space != SPACE_C21) return false; // the asynchronous step is built for the c21 space only
+    if (a.space == SPACE_RAMSEY) return ramsey_async_plan(a, ev, dyn_stride, dyn_bytes);
     if (ev.kind == 3)
         for (int l = 0; l < ev.n_layers; ++l)
-            if (ev.dims[l] % 16 != 0) return false; // its tile tasks walk K in steps of 16
+            if (ev.dims[l] % (l == 0 ? 4 : 16) != 0) return false; // tile tasks walk K in steps of 16; x is zero-padded
     if (a.B > 65536 || a.node_cap > 65536) return false; // (agent, node) are packed 16 + 16 bits in the argmin log
     size_t stride = (dyn_lds_bytes(a.n) + 15) & ~(size_t)15;
     if (ev.kind == 3) { // a waiting agent's region holds its row's activations: [x][h0][h1] + the 16-B-per-wave skew
-        size_t rows = ((size_t)((ev.dims[0] + 3) & ~3) + 2 * (size_t)ev.max_hidden) * sizeof(float) + 16 * PERSIST_WAVES;
+        size_t rows = ((size_t)((ev.dims[0] + 15) & ~15) + 2 * (size_t)ev.max_hidden) * sizeof(float) + 16 * PERSIST_WAVES;
         if (rows > stride) stride = (rows + 15) & ~(size_t)15;
     }
     size_t total = stride * PERSIST_WAVES;

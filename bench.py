@@ -226,7 +226,7 @@ def main():
         state_bytes = (space.C * space.E * 4 + 512) if wl["kind"] == "ramsey" else 0
         bytes_per_exp, d = algorithmic_bytes(c0, c1, space.STATE_DIM, space.ACTION_DIM, state_bytes)
         kw = space.KEY_WORDS
-        use_async = wl["kind"] == "c21" and not args.barrier_step  # the engine falls back to k_persist for other spaces
+        use_async = not args.barrier_step
         dims_txt = "-".join(str(x) for x in (space.STATE_DIM,) + HIDDEN + (space.ACTION_DIM,))
         launches = max(1, timing["rollout_launches"])
         avg_ms = timing["rollout_ms"] / launches

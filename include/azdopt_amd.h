@@ -190,8 +190,8 @@ typedef struct azd_engine_config {
 #define AZD_ENGINE_NO_PERSISTENT_STEP 1u
 /* The CU-resident step comes in two forms with identical results.  Default: the asynchronous one
  * (k_async: the agents of a workgroup drift apart, an agent waiting for its prediction row serves
- * MFMA tile tasks of the workgroup's evaluator; c21 space, layer widths in multiples of 16, else the
- * engine falls back by itself).  AZD_ENGINE_BARRIER_STEP selects the lock-step form (k_persist: a
+ * MFMA tile tasks of the workgroup's evaluator; hidden layer widths in multiples of 16 and an input
+ * width in multiples of 4, else the engine falls back by itself).  AZD_ENGINE_BARRIER_STEP selects the lock-step form (k_persist: a
  * workgroup barrier around the evaluator on every call), 12 % slower at 4096 agents
  * (profiles/README.md).  AZD_ENGINE_ASYNC_STEP is accepted for compatibility and changes nothing. */
 #define AZD_ENGINE_ASYNC_STEP 2u
