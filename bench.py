@@ -262,7 +262,7 @@ def main():
                          "note": "latency-bound pointer chasing: the rate target and the 40% roofline target are "
                                  "~3 orders of magnitude apart for this workload (SURVEY.md 8d)"},
         }
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and world == 1:  # timed beside the GPU run at N = 1 only
             out["cpu_baseline"] = cpu_baseline(min(os.cpu_count() or 1, 64), args.cpu_steps, wl, space.default_permitted_range())
         else:
             out["cpu_baseline"] = None
