@@ -73,3 +73,41 @@ def test_no_cpu_fallback_without_a_device():
     sp = az.ROTModifyParentsOnce(8)
     with pytest.raises(az.AzdError):
         az.NablaOptimizer(sp, None, 4)
+
+
+def test_engine_config_validation_needs_no_device():
+    """argument checks come before the device check: bad configurations are INVALID_ARGUMENT everywhere"""
+    import ctypes as C
+    import azdopt_amd as az
+    from azdopt_amd import _lib
+    L = az.lib()
+
+    def create(**kw):
+        cfg = _lib.EngineConfig()
+        cfg.space_id, cfg.n, cfg.batch = _lib.SPACE_C21, 19, 8
+        for k, v in kw.items():
+            if isinstance(v, (list, tuple)):
+                arr = getattr(cfg, k)
+                for i, x in enumerate(v):
+                    arr[i] = x
+            else:
+                setattr(cfg, k, v)
+        h = C.c_void_p()
+        st = L.azd_engine_create(C.byref(h), C.byref(cfg), None)
+        if st == 0:
+            L.azd_engine_destroy(h)
+        return st
+
+    INVALID = 1
+    assert L.azd_status_string(INVALID).decode() == "invalid argument"
+    ok = (0, 2)  # created, or "no gfx950 device" on a CPU-only box
+    assert create() in ok
+    for bad in (dict(n=3), dict(n=25), dict(batch=0), dict(space_id=7), dict(path_kind=2), dict(layers=9), dict(layers=-1)):
+        assert create(**bad) == INVALID, bad
+    ramsey = dict(space_id=_lib.SPACE_RAMSEY, n=16, n_colors=3, clique_sizes=[3, 3, 3], color_weights=[1.0, 1.0, 1.0])
+    assert create(**ramsey) in ok
+    for bad in (dict(n_colors=1), dict(n_colors=5), dict(clique_sizes=[3, 6, 3]), dict(clique_sizes=[1, 3, 3]), dict(n=24),
+                dict(n=2), dict(n=20, n_colors=4)):  # n=24: E = 276 > 256; n=20, C=4: E*C = 760 > 384
+        assert create(**{**ramsey, **bad}) == INVALID, bad
+    assert L.azd_engine_create(None, None, None) == INVALID
+    assert L.azd_ramsey_generate_roots(0, 0, 0, 1, 16, 3, 5, 200, None, None) == INVALID
