@@ -693,7 +693,7 @@ int azd_engine_par_roll_out_episodes(azd_engine *e, const uint32_t *tol, int n_t
             e->h_pargs->ev = fe;
             AZD_HIP(hipMemcpyAsync(e->d_pargs, e->h_pargs, sizeof(azd::PersistArgs), hipMemcpyHostToDevice, e->stream));
             e->time_begin(0);
-            if (use_async) azd::launch_async(e->a, e->d_pargs, k, e->d_log_key, fe.params, fe.w16, dyn_stride, dyn_bytes, e->stream);
+            if (use_async) azd::launch_async(e->a, e->d_pargs, k, e->d_log_key, fe.params, fe.wpk, dyn_stride, dyn_bytes, e->stream);
             else azd::launch_persist(e->a, e->d_pargs, k, e->d_log_key, e->d_log_node, dyn_stride, dyn_bytes, e->stream);
             e->time_end();
             e->ev->calls += (uint64_t)k;

@@ -157,6 +157,13 @@ struct FusedEval {
     // they are read; biases stay f32 in `params`
     int bf16;
     const uint16_t *w16;
+    // the asynchronous step's weight stream: the same values in MFMA-fragment order, so that one k-step
+    // of a 16-column tile is ONE contiguous piece (1 KB f32 / 512 B bf16) instead of 16 pieces of 64 B
+    // (mlp_kernels.hip:k_pack_weights).  Layer l, tile j, k-step s, lane, i = 0..3:
+    //   wpk[p_off[l] + ((j * ceil(K/16) + s) * 64 + lane) * 4 + i] = W_l[16 j + (lane & 15)][16 s + 4 (lane >> 4) + i]
+    // (0 outside the matrix); f32 words, or bf16 halves under AZD_STORAGE_BF16
+    const void *wpk;
+    long long p_off[7];
 };
 
 struct TolTable {
@@ -179,7 +186,7 @@ void launch_argmin(const Arenas &a, int init_mode, void *stream);
 void launch_observe(const Arenas &a, uint32_t n_obs_tol, void *stream);
 bool async_plan(const Arenas &a, const FusedEval &ev, uint32_t *dyn_stride, size_t *dyn_bytes);
 void launch_async(const Arenas &a, const PersistArgs *d_args, int n_calls, unsigned long long *log_key,
-                  const float *params, const uint16_t *w16, uint32_t dyn_stride, size_t dyn_bytes, void *stream);
+                  const float *params, const void *wpk, uint32_t dyn_stride, size_t dyn_bytes, void *stream);
 bool persist_plan(const Arenas &a, const FusedEval &ev, uint32_t *dyn_stride, size_t *dyn_bytes);
 void launch_persist(const Arenas &a, const PersistArgs *d_args, int n_calls, unsigned long long *log_key,
                     uint32_t *log_node, uint32_t dyn_stride, size_t dyn_bytes, void *stream);
@@ -201,7 +208,7 @@ void ramsey_launch_modify_roots(const Arenas &a, uint64_t seed, uint64_t epoch, 
                                 uint8_t *d_colors, uint64_t *d_perm, void *stream);
 bool ramsey_async_plan(const Arenas &a, const FusedEval &ev, uint32_t *dyn_stride, size_t *dyn_bytes);
 void ramsey_launch_async(const Arenas &a, const PersistArgs *d_args, int n_calls, unsigned long long *log_key,
-                         const float *params, const uint16_t *w16, uint32_t dyn_stride, size_t dyn_bytes, void *stream);
+                         const float *params, const void *wpk, uint32_t dyn_stride, size_t dyn_bytes, void *stream);
 bool ramsey_persist_plan(const Arenas &a, const FusedEval &ev, uint32_t *dyn_stride, size_t *dyn_bytes);
 void ramsey_launch_persist(const Arenas &a, const PersistArgs *d_args, int n_calls, unsigned long long *log_key,
                            uint32_t *log_node, uint32_t dyn_stride, size_t dyn_bytes, void *stream);

@@ -163,6 +163,20 @@ __global__ void k_quantize_bf16(const float *__restrict__ p, size_t n, uint16_t 
     w16[i] = (uint16_t)b;
     q[i] = __uint_as_float(b << 16);
 }
+// fragment-major copy of one layer's weights for the asynchronous step (engine_types.h:FusedEval::wpk)
+__global__ void k_pack_weights(const float *__restrict__ W, int K, int N, float *__restrict__ dst32, uint16_t *__restrict__ dst16) {
+    const int steps = (K + 15) >> 4, tiles = (N + 15) >> 4;
+    const size_t n = (size_t)tiles * steps * 256;
+    const size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= n) return;
+    const int i = (int)(e & 3), lane = (int)((e >> 2) & 63);
+    const size_t js = e >> 8;
+    const int s = (int)(js % (size_t)steps), j = (int)(js / (size_t)steps);
+    const int row = 16 * j + (lane & 15), k = 16 * s + 4 * (lane >> 4) + i;
+    const float v = (row < N && k < K) ? W[(size_t)row * K + k] : 0.f;
+    if (dst16) dst16[e] = (uint16_t)bf16_bits(v);
+    else dst32[e] = v;
+}
 __global__ void k_round_bf16(const float *__restrict__ in, size_t n, float *__restrict__ out) {
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) out[i] = bf16_round(in[i]);
@@ -275,11 +289,14 @@ struct MlpEvaluator : azd_evaluator {
     uint16_t *d_w16 = nullptr;     // bf16 copy of d_params (same offsets)
     float *d_params_q = nullptr;   // the bf16 values widened to f32 (GEMM path)
     float *d_xq = nullptr;         // input rows rounded to bf16 precision (GEMM path)
+    float *d_wpk = nullptr;        // fragment-major weights for the asynchronous step (f32 words / bf16 halves)
+    std::vector<int64_t> p_off;
+    int64_t n_packed = 0;
 
     ~MlpEvaluator() override {
         (void)hipSetDevice(device);
         if (d_w16) (void)hipFree(d_w16);
-        for (float *p : {d_params, d_grads, d_m, d_v, d_pred_train, d_delta_a, d_delta_b, d_partial, d_scalars, d_params_q, d_xq})
+        for (float *p : {d_params, d_grads, d_m, d_v, d_pred_train, d_delta_a, d_delta_b, d_partial, d_scalars, d_params_q, d_xq, d_wpk})
             if (p) (void)hipFree(p);
         for (float *p : d_act)
             if (p) (void)hipFree(p);
@@ -377,6 +394,7 @@ struct MlpEvaluator : azd_evaluator {
         k_adam<<<(unsigned)((n_params + 255) / 256), 256, 0, st>>>(d_params, d_grads, d_m, d_v, (size_t)n_params, adam.lr, adam.beta1,
                                                                   adam.beta2, adam.eps, adam.l2, bc1, bc2);
         if (bf16) requantize(st);
+        repack(st);
         AZD_HIP(hipGetLastError());
         AZD_HIP(hipMemcpyAsync(h_scalars, d_scalars, 2 * sizeof(float), hipMemcpyDeviceToHost, st));
         AZD_HIP(hipStreamSynchronize(st));
@@ -404,7 +422,19 @@ struct MlpEvaluator : azd_evaluator {
         f->max_hidden = mh;
         f->bf16 = bf16 ? 1 : 0;
         f->w16 = d_w16;
+        f->wpk = d_wpk;
+        for (int l = 0; l < L; ++l) f->p_off[l] = p_off[(size_t)l];
         return true;
+    }
+    // the asynchronous step's copy follows every change of the parameters or of the storage type
+    void repack(hipStream_t st) {
+        for (int l = 0; l < L; ++l) {
+            const int K = dims[(size_t)l], N = dims[(size_t)l + 1];
+            const size_t n = (size_t)((N + 15) >> 4) * ((K + 15) >> 4) * 256;
+            float *d32 = bf16 ? nullptr : d_wpk + p_off[(size_t)l];
+            uint16_t *d16 = bf16 ? reinterpret_cast<uint16_t *>(d_wpk) + p_off[(size_t)l] : nullptr;
+            k_pack_weights<<<(unsigned)((n + 255) / 256), 256, 0, st>>>(d_params + w_off[(size_t)l], K, N, d32, d16);
+        }
     }
     void requantize(hipStream_t st) {
         k_quantize_bf16<<<(unsigned)((n_params + 255) / 256), 256, 0, st>>>(d_params, (size_t)n_params, d_w16, d_params_q);
@@ -421,10 +451,9 @@ struct MlpEvaluator : azd_evaluator {
             AZD_HIP(hipMalloc(&d_xq, (size_t)cap_batch * dims[0] * 4));
         }
         bf16 = dtype == AZD_STORAGE_BF16;
-        if (bf16) {
-            requantize(nullptr);
-            AZD_HIP(hipDeviceSynchronize());
-        }
+        if (bf16) requantize(nullptr);
+        repack(nullptr);
+        AZD_HIP(hipDeviceSynchronize());
         return AZD_OK;
     }
     int64_t num_params() override { return n_params; }
@@ -438,10 +467,9 @@ struct MlpEvaluator : azd_evaluator {
         AZD_HIP(hipSetDevice(device));
         AZD_HIP(hipDeviceSynchronize());
         AZD_HIP(hipMemcpy(d_params, in, (size_t)n_params * 4, hipMemcpyHostToDevice));
-        if (bf16) {
-            requantize(nullptr);
-            AZD_HIP(hipDeviceSynchronize());
-        }
+        if (bf16) requantize(nullptr);
+        repack(nullptr);
+        AZD_HIP(hipDeviceSynchronize());
         return AZD_OK;
     }
 };
@@ -475,6 +503,15 @@ static int mlp_init(MlpEvaluator *m, uint64_t seed) {
         }
     }
     AZD_HIP(hipMemcpy(m->d_params, h.data(), h.size() * 4, hipMemcpyHostToDevice));
+    m->p_off.assign((size_t)m->L, 0);
+    m->n_packed = 0;
+    for (int l = 0; l < m->L; ++l) {
+        m->p_off[(size_t)l] = m->n_packed;
+        m->n_packed += (int64_t)((m->dims[(size_t)l + 1] + 15) / 16) * ((m->dims[(size_t)l] + 15) / 16) * 256;
+    }
+    AZD_HIP(hipMalloc(&m->d_wpk, (size_t)m->n_packed * 4));
+    m->repack(nullptr);
+    AZD_HIP(hipDeviceSynchronize());
     return m->ensure_batch(m->max_batch);
 }
 

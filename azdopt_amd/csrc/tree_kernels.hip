@@ -39,7 +39,7 @@ __global__ void k_hash_predictions(float *out, int batch, int action_dim, uint64
 #include "async_step.inc"
 template <class SP>
 static void l_async(const Arenas &a, const PersistArgs *d_args, int n_calls, unsigned long long *log_key,
-                    const float *params, const uint16_t *w16, uint32_t dyn_stride, size_t dyn_bytes, hipStream_t st) {
+                    const float *params, const void *wpk, uint32_t dyn_stride, size_t dyn_bytes, hipStream_t st) {
     // dynamic LDS beyond the default limit needs the attribute; ask for what this launch uses (a request
     // that cannot fit beside the kernel's static LDS fails and the error would stick to the stream)
     static size_t attr_bytes = 0;
@@ -49,13 +49,13 @@ static void l_async(const Arenas &a, const PersistArgs *d_args, int n_calls, uns
     }
     const int n_wg = (a.B + PERSIST_WAVES - 1) / PERSIST_WAVES;
     (void)hipMemsetAsync(log_key, 0xFF, (size_t)n_calls * sizeof(unsigned long long), st);
-    k_async<SP><<<dim3(n_wg), dim3(PERSIST_WAVES * 64), dyn_bytes, st>>>(d_args, n_calls, log_key, dyn_stride, params, a.state_vecs, a.h_theta, w16);
+    k_async<SP><<<dim3(n_wg), dim3(PERSIST_WAVES * 64), dyn_bytes, st>>>(d_args, n_calls, log_key, dyn_stride, params, a.state_vecs, a.h_theta, wpk);
     k_argmin_log1<SP><<<dim3(1), dim3(64), SP::dyn_bytes(a), st>>>(a, n_calls, log_key);
 }
 void launch_async(const Arenas &a, const PersistArgs *d_args, int n_calls, unsigned long long *log_key,
-                  const float *params, const uint16_t *w16, uint32_t dyn_stride, size_t dyn_bytes, void *stream) {
-    if (a.space == SPACE_RAMSEY) return ramsey_launch_async(a, d_args, n_calls, log_key, params, w16, dyn_stride, dyn_bytes, stream);
-    DISPATCH_KW(a, l_async, a, d_args, n_calls, log_key, params, w16, dyn_stride, dyn_bytes, (hipStream_t)stream);
+                  const float *params, const void *wpk, uint32_t dyn_stride, size_t dyn_bytes, void *stream) {
+    if (a.space == SPACE_RAMSEY) return ramsey_launch_async(a, d_args, n_calls, log_key, params, wpk, dyn_stride, dyn_bytes, stream);
+    DISPATCH_KW(a, l_async, a, d_args, n_calls, log_key, params, wpk, dyn_stride, dyn_bytes, (hipStream_t)stream);
 }
 // LDS plan of the asynchronous step (no evaluator buffers in LDS)
 bool async_plan(const Arenas &a, const FusedEval &ev, uint32_t *dyn_stride, size_t *dyn_bytes) {
