@@ -1,6 +1,7 @@
 set -e
 export TMPDIR=/tmp
 O=gpurun_out/final2
+rm -rf $O
 mkdir -p $O
 timeout -k 10 300 python bench.py > $O/bench_default.log 2>&1; tail -1 $O/bench_default.log | cut -c1-200
 timeout -k 10 200 python bench.py --no-cpu-baseline --barrier-step > $O/bench_barrier.log 2>&1
