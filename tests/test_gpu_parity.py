@@ -374,6 +374,43 @@ def test_persistent_step_equals_launch_per_phase(az, orc):
     assert np.max(np.abs(preds[0][1] - preds[1][1])) < MLP_ATOL
 
 
+@pytest.mark.parametrize("dtype", ["f32", "bf16"])
+def test_async_evaluator_ragged_widths(az, orc, dtype):
+    """The asynchronous step's evaluator reads a fragment-major copy of the weights, padded with zeros to
+    whole 16x16 fragments: widths that are not multiples of 16 (input 88 = 5.5 k-steps, hidden 48 and 32,
+    output 44 = 2.75 column tiles) give the same rows as the batched GEMM path, also after an optimiser step
+    and after set_params (the copy follows every change of the parameters)."""
+    n, B, seed = 11, 100, 3
+    space = az.ROTModifyParentsOnce(n)
+    assert (space.STATE_DIM, space.ACTION_DIM) == (88, 44)
+    roots = space.generate_roots(seed, B)
+    tol = MLP_ATOL if dtype == "f32" else 1e-3
+    def rows(persistent, params=None, update=False):
+        model = az.ActionModel(B, space.STATE_DIM, space.ACTION_DIM, hidden=(48, 32), seed=7, dtype=dtype)
+        if params is not None:
+            model.set_params(params)
+        o = az.NablaOptimizer.par_new(space, roots, model, B, persistent=persistent)
+        if update:
+            o.par_roll_out_episodes(TOL_REF, n_calls=3)
+            o.par_update_model(5)
+            o.par_reset_trees(roots)
+        o.par_roll_out_episodes(TOL_REF, n_calls=1)
+        if persistent:
+            assert o.counters()["EVAL_ROWS"] > 0  # the in-kernel evaluator ran, not a fallback
+        return o.state_vecs(), o.predictions(), model.get_params()
+    for update in (False, True):
+        s1, p1, w1 = rows(True, update=update)
+        s2, p2, w2 = rows(False, update=update)
+        assert np.array_equal(s1, s2)
+        assert np.max(np.abs(w1 - w2)) < 1e-6
+        assert np.max(np.abs(p1 - p2)) < tol, update
+    rng = np.random.default_rng(0)
+    w = (rng.standard_normal(w1.shape) * 0.2).astype(np.float32)
+    s1, p1, _ = rows(True, params=w)
+    s2, p2, _ = rows(False, params=w)
+    assert np.array_equal(s1, s2) and np.max(np.abs(p1 - p2)) < tol
+
+
 def test_reference_cost_vectors_on_the_device(az, orc):
     """The reference's own cost vectors through the device functions (node mode and full mode):
     star K_{1,4}: lambda_1 = 2, mu = 1; path P5: lambda_1 = 2 cos(pi/6), mu = 2 (ordered_edge.rs:198-234);
