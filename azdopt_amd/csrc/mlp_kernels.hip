@@ -36,8 +36,14 @@ enum { EPI_NONE = 0, EPI_BIAS_ACT = 1, EPI_RELU_MASK = 2, EPI_BIAS_ACT_BF16 = 3 
 // 256 threads = 4 waves in a 2x2 grid of 32x32 accumulators (v_mfma_f32_32x32x2_f32).
 template <bool A_KC, bool B_KC>
 __global__ __launch_bounds__(256) void k_gemm(const float *__restrict__ A, int lda, const float *__restrict__ B, int ldb,
-                                              float *__restrict__ C, int ldc, int M, int N, int K, int epi, int act,
-                                              const float *__restrict__ bias, const float *__restrict__ aux, int ldaux) {
+                                              float *__restrict__ C, int ldc, int M, int N, int K_all, int epi, int act,
+                                              const float *__restrict__ bias, const float *__restrict__ aux, int ldaux,
+                                              int k_split, size_t c_split_stride) {
+    // split K (gridDim.z > 1): block z accumulates k in [z * k_split, (z + 1) * k_split) into its own copy of C
+    // (k_split is a multiple of BK); the copies are added up in a fixed order afterwards (k_sum_splits)
+    const int k_begin = (int)blockIdx.z * k_split;
+    const int K = (k_begin + k_split < K_all) ? k_begin + k_split : K_all;
+    C += (size_t)blockIdx.z * c_split_stride;
     __shared__ float sA[BK][LDS_LD];
     __shared__ float sB[BK][LDS_LD];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -47,7 +53,7 @@ __global__ __launch_bounds__(256) void k_gemm(const float *__restrict__ A, int l
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[r] = 0.f;
 
-    for (int k0 = 0; k0 < K; k0 += BK) {
+    for (int k0 = k_begin; k0 < K; k0 += BK) {
         // ---- stage A tile: BM x BK
         if (A_KC) {
             int i = tid >> 2, kq = (tid & 3) * 4; // 64 rows x 4 quads
@@ -233,13 +239,18 @@ __global__ void k_loss_delta(const float *__restrict__ pred, const float *__rest
     if (threadIdx.x == 0) partial[blockIdx.x] = s[0];
 }
 // db[j] = sum_i dZ[i][j]: 64 columns x 16 row-strides per block, fixed-order LDS tree over the strides
-__global__ __launch_bounds__(1024) void k_col_sum(const float *__restrict__ dz, int M, int N, float *__restrict__ out) {
+// (gridDim.y > 1: block y sums rows [y * rows_per, (y + 1) * rows_per) into part y of `out`; k_sum_splits adds
+// the parts in order)
+__global__ __launch_bounds__(1024) void k_col_sum(const float *__restrict__ dz, int M, int N, float *__restrict__ out, int rows_per) {
     __shared__ float s[16][65];
     const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
     const int j = blockIdx.x * 64 + tx;
+    const int r0 = (int)blockIdx.y * rows_per;
+    const int r1 = (r0 + rows_per < M) ? r0 + rows_per : M;
+    out += (size_t)blockIdx.y * N;
     float acc = 0.f;
     if (j < N)
-        for (int i = ty; i < M; i += 16) acc += dz[(size_t)i * N + j];
+        for (int i = r0 + ty; i < r1; i += 16) acc += dz[(size_t)i * N + j];
     s[ty][tx] = acc;
     __syncthreads();
     for (int off = 8; off > 0; off >>= 1) {
@@ -266,7 +277,36 @@ template <bool A_KC, bool B_KC>
 static void gemm(hipStream_t st, const float *A, int lda, const float *B, int ldb, float *C, int ldc, int M, int N, int K,
                  int epi, int act, const float *bias, const float *aux, int ldaux) {
     dim3 grid((N + BN - 1) / BN, (M + BM - 1) / BM);
-    k_gemm<A_KC, B_KC><<<grid, dim3(256), 0, st>>>(A, lda, B, ldb, C, ldc, M, N, K, epi, act, bias, aux, ldaux);
+    k_gemm<A_KC, B_KC><<<grid, dim3(256), 0, st>>>(A, lda, B, ldb, C, ldc, M, N, K, epi, act, bias, aux, ldaux, K, 0);
+}
+
+// C = sum over splits, in split order: the same result whatever the schedule (every rank of a multi-GPU run
+// must take the identical optimiser step)
+__global__ void k_sum_splits(const float *__restrict__ parts, size_t n, int splits, float *__restrict__ C) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    float acc = parts[i];
+    for (int z = 1; z < splits; ++z) acc += parts[(size_t)z * n + i];
+    C[i] = acc;
+}
+// dW[out][in] = dZ^T . X with the batch as K: a 64x64-tiled grid of (out/64) x (in/64) workgroups is 20 for a
+// 256x304 layer, each walking the whole batch; K is split over gridDim.z instead and the parts are summed
+// in order (C contiguous, ldc == N)
+constexpr int GEMM_SPLIT_K = 512;
+static void gemm_dw(hipStream_t st, const float *dz, int out, const float *x, int in, float *dW, int batch, float *parts, int max_splits) {
+    int splits = (batch + GEMM_SPLIT_K - 1) / GEMM_SPLIT_K;
+    if (splits > max_splits) splits = max_splits;
+    if (splits <= 1 || !parts) {
+        gemm<false, false>(st, dz, out, x, in, dW, in, out, in, batch, EPI_NONE, 0, nullptr, nullptr, 0);
+        return;
+    }
+    int k_split = (batch + splits - 1) / splits;
+    k_split = (k_split + BK - 1) / BK * BK;
+    splits = (batch + k_split - 1) / k_split;
+    const size_t n = (size_t)out * in;
+    dim3 grid((in + BN - 1) / BN, (out + BM - 1) / BM, splits);
+    k_gemm<false, false><<<grid, dim3(256), 0, st>>>(dz, out, x, in, parts, in, out, in, batch, EPI_NONE, 0, nullptr, nullptr, 0, k_split, n);
+    k_sum_splits<<<(unsigned)((n + 255) / 256), 256, 0, st>>>(parts, n, splits, dW);
 }
 
 struct MlpEvaluator : azd_evaluator {
@@ -289,6 +329,8 @@ struct MlpEvaluator : azd_evaluator {
     uint16_t *d_w16 = nullptr;     // bf16 copy of d_params (same offsets)
     float *d_params_q = nullptr;   // the bf16 values widened to f32 (GEMM path)
     float *d_xq = nullptr;         // input rows rounded to bf16 precision (GEMM path)
+    float *d_split = nullptr;      // split-K parts of the largest weight gradient (gemm_dw)
+    static constexpr int MAX_SPLITS = 64;
     float *d_wpk = nullptr;        // fragment-major weights for the asynchronous step (f32 words / bf16 halves)
     std::vector<int64_t> p_off;
     int64_t n_packed = 0;
@@ -296,7 +338,7 @@ struct MlpEvaluator : azd_evaluator {
     ~MlpEvaluator() override {
         (void)hipSetDevice(device);
         if (d_w16) (void)hipFree(d_w16);
-        for (float *p : {d_params, d_grads, d_m, d_v, d_pred_train, d_delta_a, d_delta_b, d_partial, d_scalars, d_params_q, d_xq, d_wpk})
+        for (float *p : {d_params, d_grads, d_m, d_v, d_pred_train, d_delta_a, d_delta_b, d_partial, d_scalars, d_params_q, d_xq, d_wpk, d_split})
             if (p) (void)hipFree(p);
         for (float *p : d_act)
             if (p) (void)hipFree(p);
@@ -379,8 +421,18 @@ struct MlpEvaluator : azd_evaluator {
             const int in = dims[(size_t)l], out = dims[(size_t)l + 1];
             const float *x = (l == 0) ? d_s : d_act[(size_t)l];
             // dW[out][in] = dZ^T[out][batch] . X[batch][in]
-            gemm<false, false>(st, dz, out, x, in, d_grads + w_off[(size_t)l], in, out, in, batch, EPI_NONE, 0, nullptr, nullptr, 0);
-            k_col_sum<<<(out + 63) / 64, 1024, 0, st>>>(dz, batch, out, d_grads + b_off[(size_t)l]);
+            gemm_dw(st, dz, out, x, in, d_grads + w_off[(size_t)l], batch, d_split, MAX_SPLITS);
+            {   // db[out] = column sums of dZ, the batch split like the weight gradient's K
+                int parts = (batch + GEMM_SPLIT_K - 1) / GEMM_SPLIT_K;
+                parts = parts > MAX_SPLITS ? MAX_SPLITS : parts;
+                if (parts <= 1) k_col_sum<<<(out + 63) / 64, 1024, 0, st>>>(dz, batch, out, d_grads + b_off[(size_t)l], batch);
+                else {
+                    const int rows_per = (batch + parts - 1) / parts;
+                    parts = (batch + rows_per - 1) / rows_per;
+                    k_col_sum<<<dim3((out + 63) / 64, parts), 1024, 0, st>>>(dz, batch, out, d_split, rows_per);
+                    k_sum_splits<<<(out + 255) / 256, 256, 0, st>>>(d_split, (size_t)out, parts, d_grads + b_off[(size_t)l]);
+                }
+            }
             if (l > 0) {
                 // dX[batch][in] = (dZ[batch][out] . W[out][in]) masked by ReLU'(x)
                 gemm<true, false>(st, dz, out, d_params + w_off[(size_t)l], in, dx, in, batch, in, out, EPI_RELU_MASK, 0, nullptr, x, in);
@@ -510,6 +562,14 @@ static int mlp_init(MlpEvaluator *m, uint64_t seed) {
         m->n_packed += (int64_t)((m->dims[(size_t)l + 1] + 15) / 16) * ((m->dims[(size_t)l] + 15) / 16) * 256;
     }
     AZD_HIP(hipMalloc(&m->d_wpk, (size_t)m->n_packed * 4));
+    {
+        size_t big = 0;
+        for (int l = 0; l < m->L; ++l) {
+            const size_t n = (size_t)m->dims[(size_t)l] * m->dims[(size_t)l + 1];
+            big = n > big ? n : big;
+        }
+        AZD_HIP(hipMalloc(&m->d_split, big * MlpEvaluator::MAX_SPLITS * 4));
+    }
     m->repack(nullptr);
     AZD_HIP(hipDeviceSynchronize());
     return m->ensure_batch(m->max_batch);
