@@ -266,9 +266,10 @@ def test_mlp_forward_matches_cpu(az, orc):
         assert np.max(np.abs(y - t.numpy())) < MLP_ATOL
 
 
-def test_mlp_update_matches_cpu_and_torch(az, orc):
+@pytest.mark.parametrize("B", [512, 1300])  # 1300 rows: the gradient reductions run as three ragged parts of the batch
+def test_mlp_update_matches_cpu_and_torch(az, orc, B):
     import torch
-    dims, B = (304, 256, 256, 256, 152), 512
+    dims = (304, 256, 256, 256, 152)
     cfg = dict(lr=1e-3, betas=(0.9, 0.999), eps=1e-8, l2=1e-6)
     m = az.ActionModel(B, dims[0], dims[-1], hidden=dims[1:-1], seed=5, **cfg)
     om = orc.Mlp(dims, lr=cfg["lr"], l2=cfg["l2"], seed=5, threads=8)
@@ -372,6 +373,24 @@ def test_persistent_step_equals_launch_per_phase(az, orc):
         preds.append((o.state_vecs(), o.predictions()))
     assert np.array_equal(preds[0][0], preds[1][0])
     assert np.max(np.abs(preds[0][1] - preds[1][1])) < MLP_ATOL
+
+
+def test_mlp_update_is_deterministic(az):
+    """The optimiser step is a pure function of (parameters, batch): two evaluators fed the same rows end
+    with bit-identical parameters (the batch-split gradient reductions add their parts in a fixed order), which
+    is what keeps the replicas of a multi-GPU run in lock-step without a parameter broadcast."""
+    dims, B = (304, 256, 256, 256, 152), 5000
+    rng = np.random.default_rng(1)
+    x = (rng.random((B, dims[0])) < 0.3).astype(np.float32)
+    obs = rng.random((B, dims[-1]), dtype=np.float32)
+    w = (rng.random((B, dims[-1])) < 0.05).astype(np.float32)
+    params = []
+    for rep in range(2):
+        m = az.ActionModel(B, dims[0], dims[-1], hidden=dims[1:-1], seed=11)
+        for it in range(3):
+            m.update_model(x, obs, w)
+        params.append(m.get_params())
+    assert np.array_equal(params[0].view(np.uint32), params[1].view(np.uint32))
 
 
 @pytest.mark.parametrize("dtype", ["f32", "bf16"])
