@@ -375,6 +375,38 @@ def test_persistent_step_equals_launch_per_phase(az, orc):
     assert np.max(np.abs(preds[0][1] - preds[1][1])) < MLP_ATOL
 
 
+def test_async_epoch_is_reproducible_at_full_size(az):
+    """BASELINE config B for a whole epoch (4096 agents, 800 calls in one launch, the MLP in the kernel): which rows
+    share a batch and which wave computes which tile depends on timing, the results must not -- two runs
+    give the same counters, argmin, predictions and trees, and so does the barrier step."""
+    n, B, calls = 19, 4096, 800
+    space = az.ROTModifyParentsOnce(n)
+    roots = space.generate_roots(0, B)
+    runs = []
+    for async_step in (True, True, False):
+        model = az.ActionModel(B, space.STATE_DIM, space.ACTION_DIM, hidden=(256, 256, 256), seed=0)
+        o = az.NablaOptimizer.par_new(space, roots, model, B, async_step=async_step)
+        imp = o.par_roll_out_episodes(TOL_REF, n_calls=calls)
+        runs.append((o, imp))
+    o0, i0 = runs[0]
+    c0, a0 = o0.counters(), o0.argmin_data()
+    assert c0["EXPANSIONS"] > 0.8 * B * calls and c0["EVAL_ROWS"] == c0["EXPANSIONS"]
+    for o, imp in runs[1:]:
+        c, am = o.counters(), o.argmin_data()
+        assert imp == i0
+        for k in MAIN_CTRS:
+            assert c[k] == c0[k], k
+        assert (am.eval, am.agent, am.node) == (a0.eval, a0.agent, a0.node)
+        assert np.array_equal(o.state_vecs(), o0.state_vecs())
+        assert np.array_equal(o.predictions().view(np.uint32), o0.predictions().view(np.uint32))
+        for i in range(0, B, 257):
+            t1, t2 = o.get_tree(i), o0.get_tree(i)
+            for f in t1.FIELDS:
+                x, y = getattr(t1, f), getattr(t2, f)
+                assert x.shape == y.shape and np.array_equal(x.view(np.uint32) if x.dtype.kind == "f" else x,
+                                                             y.view(np.uint32) if y.dtype.kind == "f" else y), (i, f)
+
+
 def test_mlp_update_is_deterministic(az):
     """The optimiser step is a pure function of (parameters, batch): two evaluators fed the same rows end
     with bit-identical parameters (the batch-split gradient reductions add their parts in a fixed order), which
