@@ -181,3 +181,42 @@ def test_ramsey_topology_parity_with_mlp_predictions(az, orc, persistent):
         assert_tree_equal(opt.get_tree(i), oe.export_tree(i), f"agent {i}")
     loss = opt.par_update_model(5)
     assert np.isfinite(loss)
+
+
+@pytest.mark.parametrize("dtype", ["f32", "bf16"])
+def test_ramsey_epoch_is_reproducible_at_full_size(az, dtype):
+    """BASELINE config D per GPU (r333, N = 16, 8192 agents = two rounds of workgroups) for an epoch of 400 calls
+    in one launch with the MLP in the kernel: batching depends on timing, results must not -- two asynchronous
+    runs and (f32) the barrier step give the same counters, argmin, predictions and trees."""
+    n, sizes, B, calls = 16, [3, 3, 3], 8192, 400
+    tol = ([200, 200, 200, 100, 100, 100, 50, 50, 50, 25, 25, 25], 10)
+    space = az.RamseySpaceNoEdgeRecolor(n, sizes)
+    roots = space.generate_roots(0, B)
+    forms = (True, True, False) if dtype == "f32" else (True, True)  # the barrier step has no bf16 evaluator
+    runs = []
+    for async_step in forms:
+        model = az.ActionModel(B, space.STATE_DIM, space.ACTION_DIM, hidden=(256, 256, 256), seed=0, dtype=dtype)
+        o = az.NablaOptimizer.par_new(space, roots, model, B, async_step=async_step)
+        imp = o.par_roll_out_episodes(tol, n_calls=calls)
+        runs.append((o, imp))
+    o0, i0 = runs[0]
+    c0, a0 = o0.counters(), o0.argmin_data()
+    assert c0["EXPANSIONS"] > 0.5 * B * calls and c0["EVAL_ROWS"] == c0["EXPANSIONS"]
+    for o, imp in runs[1:]:
+        c, am = o.counters(), o.argmin_data()
+        assert imp == i0
+        for k in ("EXPANSIONS", "TERMINALS", "TRANSPOSITIONS", "VISITED_STEPS", "SELECT_CALLS"):
+            assert c[k] == c0[k], k
+        assert (am.eval, am.agent, am.node) == (a0.eval, a0.agent, a0.node)
+        assert np.array_equal(o.state_vecs().view(np.uint32), o0.state_vecs().view(np.uint32))
+        p1, p0 = o.predictions().view(np.uint32), o0.predictions().view(np.uint32)
+        assert np.array_equal(p1, p0)
+        for i in range(0, B, 511):
+            t1, t2 = o.get_tree(i), o0.get_tree(i)
+            for f in t1.FIELDS:
+                x, y = getattr(t1, f), getattr(t2, f)
+                xn, yn = (np.isnan(x), np.isnan(y)) if x.dtype.kind == "f" else (None, None)
+                if xn is not None:
+                    assert np.array_equal(xn, yn), (i, f)
+                    x, y = np.where(xn, 0, x), np.where(yn, 0, y)
+                assert x.shape == y.shape and np.array_equal(x, y), (i, f)
