@@ -10,7 +10,7 @@ import torch
 import azdopt_amd as az
 
 S, A = 304, 152
-for B in (4096, 8192, 16384, 32768):
+for B in (4096, 8192, 16384, 32768, 65536):
     model = az.ActionModel(B, S, A, hidden=(256, 256, 256), seed=1)
     g = torch.Generator(device="cuda").manual_seed(0)
     s = (torch.rand(B, S, device="cuda", generator=g) < 0.1).float()
