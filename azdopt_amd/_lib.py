@@ -108,6 +108,7 @@ def lib():
     sig("azd_engine_par_new", C.c_int, vp, vp, vp)
     sig("azd_engine_par_roll_out_episodes", C.c_int, vp, vp, C.c_int, C.c_uint32, C.c_int, i32p)
     sig("azd_engine_par_update_model", C.c_int, vp, C.c_uint32, f32p)
+    sig("azd_engine_par_update_model_sharded", C.c_int, vp, C.c_uint32, vp, f32p)
     sig("azd_engine_par_reset_trees", C.c_int, vp, vp, vp)
     sig("azd_engine_argmin_data", C.c_int, vp, C.POINTER(Argmin))
     sig("azd_engine_agent_counters", C.c_int, vp, vp)
@@ -140,6 +141,7 @@ def lib():
     sig("azd_engine_set_timing", C.c_int, vp, C.c_int)
     sig("azd_engine_timing", C.c_int, vp, C.POINTER(C.c_double), C.POINTER(C.c_double), u64p)
     sig("azd_engine_stream", vp, vp)
+    sig("azd_engine_step_form", C.c_int, vp, i32p, C.POINTER(C.c_char_p))
     sig("azd_debug_probe_math", C.c_int, C.c_int, vp, vp, C.c_int)
     sig("azd_debug_probe_cost", C.c_int, C.c_int, vp, C.c_int, C.c_int, C.c_int, C.c_int, vp, vp, f32p)
     _LIB = L

@@ -3,6 +3,8 @@
 // No CPU fallback: every compute entry point needs a gfx950 device.
 #include <hip/hip_runtime.h>
 
+#include <dlfcn.h>
+
 #include <algorithm>
 #include <cstdio>
 #include <cstring>
@@ -133,6 +135,10 @@ struct azd_engine {
     unsigned long long *d_log_key = nullptr;
     uint32_t *d_log_node = nullptr;
     int log_calls = 0;
+    float *d_pool = nullptr;      // pooled training triple of all ranks (azd_engine_par_update_model_sharded)
+    size_t pool_rows = 0;
+    int step_form = 0;            // AZD_STEP_* chosen by the last par_roll_out_episodes
+    std::string step_reason;      // why the faster forms were not taken ("" if the asynchronous step ran)
 
     template <typename T>
     int alloc(T **p, size_t count) {
@@ -594,6 +600,7 @@ int azd_engine_destroy(azd_engine *e) {
     if (e->h_status) (void)hipHostFree(e->h_status);
     if (e->h_argmin) (void)hipHostFree(e->h_argmin);
     if (e->h_pargs) (void)hipHostFree(e->h_pargs);
+    if (e->d_pool) (void)hipFree(e->d_pool);
     for (auto &it : e->ev_inflight) {
         (void)hipEventDestroy(it.second.first);
         (void)hipEventDestroy(it.second.second);
@@ -678,8 +685,20 @@ int azd_engine_par_roll_out_episodes(azd_engine *e, const uint32_t *tol, int n_t
     uint32_t dyn_stride = 0;
     size_t dyn_bytes = 0;
     const bool fusable = e->persist_enabled && e->ev->fused_desc(&fe);
-    const bool use_async = fusable && !e->barrier_step && azd::async_plan(e->a, fe, &dyn_stride, &dyn_bytes);
-    const bool use_barrier = fusable && !use_async && azd::persist_plan(e->a, fe, &dyn_stride, &dyn_bytes);
+    const char *why_a = "", *why_b = "";
+    const bool use_async = fusable && !e->barrier_step && azd::async_plan(e->a, fe, &dyn_stride, &dyn_bytes, &why_a);
+    const bool use_barrier = fusable && !use_async && azd::persist_plan(e->a, fe, &dyn_stride, &dyn_bytes, &why_b);
+    // which form runs is part of the result a caller may want to check (azd_engine_step_form): the launch-per-phase
+    // form is several times slower than the CU-resident ones
+    e->step_form = use_async ? AZD_STEP_ASYNC : use_barrier ? AZD_STEP_BARRIER : AZD_STEP_PER_CALL;
+    e->step_reason.clear();
+    if (!use_async) {
+        if (!e->persist_enabled) e->step_reason = "AZD_ENGINE_NO_PERSISTENT_STEP";
+        else if (!fusable) e->step_reason = "the evaluator cannot run inside the kernel (external model, more than 7 layers, or a layer width that is not a multiple of 4)";
+        else if (e->barrier_step) e->step_reason = "AZD_ENGINE_BARRIER_STEP";
+        else e->step_reason = why_a;
+        if (fusable && !use_barrier && *why_b) e->step_reason += std::string("; ") + why_b;
+    }
     if (use_async || use_barrier) {
         // CU-resident forms: the whole call chain, n_calls times, in one launch per <= log_calls calls
         int left = n_calls;
@@ -747,6 +766,84 @@ int azd_engine_par_update_model(azd_engine *e, uint32_t n_obs_tol, float *loss) 
     AZD_HIP(hipGetLastError());
     float l = 0.f;
     int st = e->ev->update_model_dev(e->a.B, e->a.state_vecs, e->a.obs, e->a.weights, &l, e->stream); // :279-280
+    if (st) return st;
+    AZD_HIP(hipStreamSynchronize(e->stream));
+    if (loss) *loss = l;
+    return AZD_OK;
+}
+
+// ---- the epoch exchange of a sharded population, for hosts that are not Python (azdopt_amd/parallel.py does the
+// same through torch.distributed): optimizer/mod.rs:249-281 where the batch is the union of all ranks' agents.
+// RCCL is bound at first use (dlopen), so the library carries no link-time dependency on it.
+namespace {
+struct RcclApi {
+    void *lib = nullptr;
+    int (*allGather)(const void *, void *, size_t, int, void *, hipStream_t) = nullptr;
+    int (*commCount)(void *, int *) = nullptr;
+    const char *(*errorString)(int) = nullptr;
+    bool tried = false;
+};
+RcclApi *rccl() {
+    static RcclApi api;
+    if (!api.tried) {
+        api.tried = true;
+        for (const char *name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) {
+            api.lib = dlopen(name, RTLD_NOW | RTLD_GLOBAL);
+            if (api.lib) break;
+        }
+        if (api.lib) {
+            api.allGather = (decltype(api.allGather))dlsym(api.lib, "ncclAllGather");
+            api.commCount = (decltype(api.commCount))dlsym(api.lib, "ncclCommCount");
+            api.errorString = (decltype(api.errorString))dlsym(api.lib, "ncclGetErrorString");
+        }
+    }
+    return &api;
+}
+constexpr int NCCL_FLOAT32 = 7; // ncclFloat32 (rccl.h)
+} // namespace
+
+int azd_engine_par_update_model_sharded(azd_engine *e, uint32_t n_obs_tol, void *nccl_comm, float *loss) {
+    if (!e || !e->initialised || !nccl_comm) return AZD_ERR_INVALID_ARGUMENT;
+    if (!e->ev) return AZD_ERR_NO_EVALUATOR;
+    AZD_HIP(hipSetDevice(e->cfg.device));
+    RcclApi &api = *rccl();
+    if (!api.allGather || !api.commCount) {
+        azd::g_last_error = "librccl.so could not be loaded (ncclAllGather / ncclCommCount)";
+        return AZD_ERR_UNSUPPORTED;
+    }
+    int world = 0;
+    int rc = api.commCount(nccl_comm, &world);
+    if (rc != 0 || world <= 0) {
+        azd::g_last_error = std::string("ncclCommCount: ") + (api.errorString ? api.errorString(rc) : "failed");
+        return AZD_ERR_INVALID_ARGUMENT;
+    }
+    const azd::Arenas &a = e->a;
+    const size_t B = (size_t)a.B, rows = B * (size_t)world;
+    const size_t ns = rows * a.S, na = rows * a.A;
+    if (rows > e->pool_rows) {
+        if (e->d_pool) (void)hipFree(e->d_pool);
+        e->d_pool = nullptr;
+        e->pool_rows = 0;
+        AZD_HIP(hipMalloc(&e->d_pool, (ns + 2 * na) * sizeof(float)));
+        e->pool_rows = rows;
+    }
+    float *g_sv = e->d_pool, *g_obs = g_sv + ns, *g_w = g_obs + na;
+    azd::launch_observe(a, n_obs_tol, e->stream); // :262-278 on this rank's trees
+    AZD_HIP(hipGetLastError());
+    // rank order = global agent order (shards are contiguous agent ranges); the collectives run on the engine's
+    // stream, behind k_observe and ahead of the optimiser step
+    const float *src[3] = {a.state_vecs, a.obs, a.weights};
+    float *dst[3] = {g_sv, g_obs, g_w};
+    const size_t cnt[3] = {B * (size_t)a.S, B * (size_t)a.A, B * (size_t)a.A};
+    for (int i = 0; i < 3; ++i) {
+        rc = api.allGather(src[i], dst[i], cnt[i], NCCL_FLOAT32, nccl_comm, e->stream);
+        if (rc != 0) {
+            azd::g_last_error = std::string("ncclAllGather: ") + (api.errorString ? api.errorString(rc) : "failed");
+            return AZD_ERR_HIP;
+        }
+    }
+    float l = 0.f;
+    int st = e->ev->update_model_dev((int)rows, g_sv, g_obs, g_w, &l, e->stream); // :279-280, the same step on every rank
     if (st) return st;
     AZD_HIP(hipStreamSynchronize(e->stream));
     if (loss) *loss = l;
@@ -1019,6 +1116,12 @@ int azd_engine_timing(azd_engine *e, double *tree_ms, double *evaluator_ms, uint
     return AZD_OK;
 }
 void *azd_engine_stream(azd_engine *e) { return e ? (void *)e->stream : nullptr; }
+int azd_engine_step_form(azd_engine *e, int *form, const char **reason) {
+    if (!e) return AZD_ERR_INVALID_ARGUMENT;
+    if (form) *form = e->step_form;
+    if (reason) *reason = e->step_reason.c_str();
+    return AZD_OK;
+}
 
 int azd_debug_probe_math(int device, const float *in, float *out, int n) {
     if (!in || !out || n <= 0) return AZD_ERR_INVALID_ARGUMENT;

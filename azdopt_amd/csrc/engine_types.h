@@ -151,6 +151,10 @@ struct FusedEval {
     int dims[8];
     int final_act;
     int max_hidden;
+    // the two ping-pong activation buffers of a row are sized independently: layer l < L-1 writes its output to
+    // buffer l & 1, so buffer 0 holds the widest EVEN-layer output and buffer 1 the widest ODD-layer output
+    // (04-c21-tree.rs:46-52: 304-512-1024-512-152 needs 512 + 1024 floats, not 2 x 1024)
+    int hid[2];
     long long w_off[7], b_off[7];
     // bf16 weight storage (AZD_STORAGE_BF16): the same layout as `params` in 16-bit words; products are
     // exact in f32, accumulation is f32 (v_mfma_f32_16x16x16_bf16), activations are rounded to bf16 as
@@ -178,16 +182,17 @@ struct PersistArgs { // argument block of the persistent step, read from device 
     FusedEval ev;
 };
 
-// kernel launchers (tree_kernels.hip); all asynchronous on `stream`
+// kernel launchers (tree_kernels.hip); all asynchronous on `stream`.  The *_plan functions lay out the LDS of a
+// CU-resident step; when the model or the population does not fit they return false and say why in *why.
 void launch_init_roots(const Arenas &a, const uint8_t *d_parents, const uint64_t *d_permitted, void *stream);
 void launch_add_actions(const Arenas &a, int root_mode, void *stream);
 void launch_rollout(const Arenas &a, const TolTable &tol, void *stream);
 void launch_argmin(const Arenas &a, int init_mode, void *stream);
 void launch_observe(const Arenas &a, uint32_t n_obs_tol, void *stream);
-bool async_plan(const Arenas &a, const FusedEval &ev, uint32_t *dyn_stride, size_t *dyn_bytes);
+bool async_plan(const Arenas &a, const FusedEval &ev, uint32_t *dyn_stride, size_t *dyn_bytes, const char **why = nullptr);
 void launch_async(const Arenas &a, const PersistArgs *d_args, int n_calls, unsigned long long *log_key,
                   const float *params, const void *wpk, uint32_t dyn_stride, size_t dyn_bytes, void *stream);
-bool persist_plan(const Arenas &a, const FusedEval &ev, uint32_t *dyn_stride, size_t *dyn_bytes);
+bool persist_plan(const Arenas &a, const FusedEval &ev, uint32_t *dyn_stride, size_t *dyn_bytes, const char **why = nullptr);
 void launch_persist(const Arenas &a, const PersistArgs *d_args, int n_calls, unsigned long long *log_key,
                     uint32_t *log_node, uint32_t dyn_stride, size_t dyn_bytes, void *stream);
 void launch_c21_modify_roots(const Arenas &a, uint64_t seed, uint64_t epoch, uint64_t first_agent, int kmin, int kmax,
@@ -206,10 +211,10 @@ void ramsey_launch_argmin(const Arenas &a, int init_mode, void *stream);
 void ramsey_launch_observe(const Arenas &a, uint32_t n_obs_tol, void *stream);
 void ramsey_launch_modify_roots(const Arenas &a, uint64_t seed, uint64_t epoch, uint64_t first_agent, int kmin, int kmax,
                                 uint8_t *d_colors, uint64_t *d_perm, void *stream);
-bool ramsey_async_plan(const Arenas &a, const FusedEval &ev, uint32_t *dyn_stride, size_t *dyn_bytes);
+bool ramsey_async_plan(const Arenas &a, const FusedEval &ev, uint32_t *dyn_stride, size_t *dyn_bytes, const char **why = nullptr);
 void ramsey_launch_async(const Arenas &a, const PersistArgs *d_args, int n_calls, unsigned long long *log_key,
                          const float *params, const void *wpk, uint32_t dyn_stride, size_t dyn_bytes, void *stream);
-bool ramsey_persist_plan(const Arenas &a, const FusedEval &ev, uint32_t *dyn_stride, size_t *dyn_bytes);
+bool ramsey_persist_plan(const Arenas &a, const FusedEval &ev, uint32_t *dyn_stride, size_t *dyn_bytes, const char **why = nullptr);
 void ramsey_launch_persist(const Arenas &a, const PersistArgs *d_args, int n_calls, unsigned long long *log_key,
                            uint32_t *log_node, uint32_t dyn_stride, size_t dyn_bytes, void *stream);
 

@@ -472,6 +472,9 @@ struct MlpEvaluator : azd_evaluator {
             if (l >= 1 && dims[(size_t)l] > mh) mh = dims[(size_t)l];
         }
         f->max_hidden = mh;
+        f->hid[0] = f->hid[1] = 16;
+        for (int l = 0; l + 1 < L; ++l)
+            if (dims[(size_t)l + 1] > f->hid[l & 1]) f->hid[l & 1] = dims[(size_t)l + 1];
         f->bf16 = bf16 ? 1 : 0;
         f->w16 = d_w16;
         f->wpk = d_wpk;

@@ -27,11 +27,10 @@ namespace azd {
 template <class SP>
 static void l_async(const Arenas &a, const PersistArgs *d_args, int n_calls, unsigned long long *log_key,
                     const float *params, const void *wpk, uint32_t dyn_stride, size_t dyn_bytes, hipStream_t st) {
-    static size_t attr_bytes = 0;
-    if (dyn_bytes > attr_bytes) {
-        if (hipFuncSetAttribute((const void *)k_async<SP>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn_bytes) == hipSuccess) attr_bytes = dyn_bytes;
-        else (void)hipGetLastError();
-    }
+    // dynamic LDS beyond the default 64 KB needs the attribute, which is per DEVICE (the current one): set on every
+    // launch -- a host-side call, once per <= 1024 search calls -- so that engines on several devices in one process
+    // all get it; the plans have already checked that the request fits beside the kernel's static LDS
+    if (hipFuncSetAttribute((const void *)k_async<SP>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn_bytes) != hipSuccess) return; // sticky: the caller's hipGetLastError reports it
     const int n_wg = (a.B + PERSIST_WAVES - 1) / PERSIST_WAVES;
     (void)hipMemsetAsync(log_key, 0xFF, (size_t)n_calls * sizeof(unsigned long long), st);
     k_async<SP><<<dim3(n_wg), dim3(PERSIST_WAVES * 64), dyn_bytes, st>>>(d_args, n_calls, log_key, dyn_stride, params, a.state_vecs, a.h_theta, wpk);
@@ -43,18 +42,29 @@ void ramsey_launch_async(const Arenas &a, const PersistArgs *d_args, int n_calls
 }
 // LDS plan of the asynchronous step: the per-wave region holds the search scratch + the clique counts
 // during a call, and the row's activations [x][h0][h1] while the agent waits
-bool ramsey_async_plan(const Arenas &a, const FusedEval &ev, uint32_t *dyn_stride, size_t *dyn_bytes) {
-    if (a.B > 65536 || a.node_cap > 65536) return false; // (agent, node) are packed 16 + 16 bits in the argmin log
+bool ramsey_async_plan(const Arenas &a, const FusedEval &ev, uint32_t *dyn_stride, size_t *dyn_bytes, const char **why) {
+    const char *dummy;
+    if (!why) why = &dummy;
+    if (a.B > 65536 || a.node_cap > 65536) { // (agent, node) are packed 16 + 16 bits in the argmin log
+        *why = "asynchronous step: more than 65536 agents or nodes per tree";
+        return false;
+    }
     size_t stride = (RamseySpace<1>::dyn_bytes(a) + 15) & ~(size_t)15;
     if (ev.kind == 3) {
         for (int l = 0; l < ev.n_layers; ++l)
-            if (ev.dims[l] % (l == 0 ? 4 : 16) != 0) return false;
-        size_t rows = ((size_t)((ev.dims[0] + 15) & ~15) + 2 * (size_t)ev.max_hidden) * sizeof(float) + 16 * PERSIST_WAVES;
+            if (ev.dims[l] % (l == 0 ? 4 : 16) != 0) {
+                *why = "asynchronous step: hidden widths must be multiples of 16 and the input width a multiple of 4";
+                return false;
+            }
+        size_t rows = ((size_t)((ev.dims[0] + 15) & ~15) + (size_t)ev.hid[0] + (size_t)ev.hid[1]) * sizeof(float) + 16 * PERSIST_WAVES;
         if (rows > stride) stride = (rows + 15) & ~(size_t)15;
     }
     const size_t total = stride * PERSIST_WAVES;
     const size_t static_lds = PERSIST_WAVES * (sizeof(RamseyLds) + 16) + sizeof(AsyncCtl) + 256;
-    if (total + static_lds > 160 * 1024) return false;
+    if (total + static_lds > 160 * 1024) {
+        *why = "asynchronous step: 16 rows of activations do not fit the CU's 160 KB of LDS";
+        return false;
+    }
     *dyn_stride = (uint32_t)stride;
     *dyn_bytes = total;
     return true;

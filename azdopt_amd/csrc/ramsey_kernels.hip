@@ -47,13 +47,10 @@ static void l_observe(const Arenas &a, uint32_t tol, hipStream_t st) {
 template <class SP>
 static void l_persist(const Arenas &a, const PersistArgs *d_args, int n_calls, unsigned long long *log_key,
                       uint32_t *log_node, uint32_t dyn_stride, size_t dyn_bytes, hipStream_t st) {
-    // dynamic LDS beyond the default limit needs the attribute; ask for what this launch uses (a request
-    // that cannot fit beside the kernel's static LDS fails and the error would stick to the stream)
-    static size_t attr_bytes = 0;
-    if (dyn_bytes > attr_bytes) {
-        if (hipFuncSetAttribute((const void *)k_persist<SP>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn_bytes) == hipSuccess) attr_bytes = dyn_bytes;
-        else (void)hipGetLastError();
-    }
+    // dynamic LDS beyond the default 64 KB needs the attribute, which is per DEVICE (the current one): set on every
+    // launch -- a host-side call, once per <= 1024 search calls -- so that engines on several devices in one process
+    // all get it; the plans have already checked that the request fits beside the kernel's static LDS
+    if (hipFuncSetAttribute((const void *)k_persist<SP>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn_bytes) != hipSuccess) return; // sticky: the caller's hipGetLastError reports it
     const int n_wg = (a.B + PERSIST_WAVES - 1) / PERSIST_WAVES;
     k_persist<SP><<<dim3(n_wg), dim3(PERSIST_WAVES * 64), dyn_bytes, st>>>(d_args, n_calls, log_key, log_node, dyn_stride);
     k_argmin_log<SP><<<dim3(1), dim3(64), SP::dyn_bytes(a), st>>>(a, n_calls, n_wg, log_key, log_node);
@@ -85,19 +82,30 @@ void ramsey_launch_observe(const Arenas &a, uint32_t n_obs_tol, void *stream) {
 }
 // LDS plan of the persistent step; false when the workgroup does not fit a CU or the in-kernel MLP
 // cannot take the layer widths (it loads rows as float4)
-bool ramsey_persist_plan(const Arenas &a, const FusedEval &ev, uint32_t *dyn_stride, size_t *dyn_bytes) {
+bool ramsey_persist_plan(const Arenas &a, const FusedEval &ev, uint32_t *dyn_stride, size_t *dyn_bytes, const char **why) {
+    const char *dummy;
+    if (!why) why = &dummy;
     size_t per = CORE_DYN_BYTES + (size_t)a.C * a.E * sizeof(int32_t);
     size_t stride = (per + 15) & ~(size_t)15;
     size_t total = stride * PERSIST_WAVES;
     if (ev.kind == 3) {
-        if (ev.bf16) return false; // bf16 weight storage is built into the asynchronous step only
+        if (ev.bf16) { // bf16 weight storage is built into the asynchronous step only
+            *why = "barrier step: bf16 weight storage is not built into it";
+            return false;
+        }
         for (int l = 0; l < ev.n_layers; ++l)
-            if (ev.dims[l] % 4 != 0) return false;
-        size_t mlp = (size_t)PERSIST_WAVES * ((size_t)(ev.dims[0] + 4) + 2 * (size_t)(ev.max_hidden + 4)) * sizeof(float);
+            if (ev.dims[l] % 4 != 0) {
+                *why = "barrier step: layer widths must be multiples of 4";
+                return false;
+            }
+        size_t mlp = (size_t)PERSIST_WAVES * ((size_t)(ev.dims[0] + 4) + (size_t)(ev.hid[0] + 4) + (size_t)(ev.hid[1] + 4)) * sizeof(float);
         if (mlp > total) total = mlp;
     }
     const size_t static_lds = PERSIST_WAVES * (sizeof(RamseyLds) + 16) + 256;
-    if (total + static_lds > 160 * 1024) return false;
+    if (total + static_lds > 160 * 1024) {
+        *why = "barrier step: 16 rows of activations do not fit the CU's 160 KB of LDS";
+        return false;
+    }
     *dyn_stride = (uint32_t)stride;
     *dyn_bytes = total;
     return true;

@@ -40,13 +40,10 @@ __global__ void k_hash_predictions(float *out, int batch, int action_dim, uint64
 template <class SP>
 static void l_async(const Arenas &a, const PersistArgs *d_args, int n_calls, unsigned long long *log_key,
                     const float *params, const void *wpk, uint32_t dyn_stride, size_t dyn_bytes, hipStream_t st) {
-    // dynamic LDS beyond the default limit needs the attribute; ask for what this launch uses (a request
-    // that cannot fit beside the kernel's static LDS fails and the error would stick to the stream)
-    static size_t attr_bytes = 0;
-    if (dyn_bytes > attr_bytes) {
-        if (hipFuncSetAttribute((const void *)k_async<SP>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn_bytes) == hipSuccess) attr_bytes = dyn_bytes;
-        else (void)hipGetLastError();
-    }
+    // dynamic LDS beyond the default 64 KB needs the attribute, which is per DEVICE (the current one): set on every
+    // launch -- a host-side call, once per <= 1024 search calls -- so that engines on several devices in one process
+    // all get it; the plans have already checked that the request fits beside the kernel's static LDS
+    if (hipFuncSetAttribute((const void *)k_async<SP>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn_bytes) != hipSuccess) return; // sticky: the caller's hipGetLastError reports it
     const int n_wg = (a.B + PERSIST_WAVES - 1) / PERSIST_WAVES;
     (void)hipMemsetAsync(log_key, 0xFF, (size_t)n_calls * sizeof(unsigned long long), st);
     k_async<SP><<<dim3(n_wg), dim3(PERSIST_WAVES * 64), dyn_bytes, st>>>(d_args, n_calls, log_key, dyn_stride, params, a.state_vecs, a.h_theta, wpk);
@@ -58,20 +55,31 @@ void launch_async(const Arenas &a, const PersistArgs *d_args, int n_calls, unsig
     DISPATCH_KW(a, l_async, a, d_args, n_calls, log_key, params, wpk, dyn_stride, dyn_bytes, (hipStream_t)stream);
 }
 // LDS plan of the asynchronous step (no evaluator buffers in LDS)
-bool async_plan(const Arenas &a, const FusedEval &ev, uint32_t *dyn_stride, size_t *dyn_bytes) {
-    if (a.space == SPACE_RAMSEY) return ramsey_async_plan(a, ev, dyn_stride, dyn_bytes);
+bool async_plan(const Arenas &a, const FusedEval &ev, uint32_t *dyn_stride, size_t *dyn_bytes, const char **why) {
+    const char *dummy;
+    if (!why) why = &dummy;
+    if (a.space == SPACE_RAMSEY) return ramsey_async_plan(a, ev, dyn_stride, dyn_bytes, why);
     if (ev.kind == 3)
         for (int l = 0; l < ev.n_layers; ++l)
-            if (ev.dims[l] % (l == 0 ? 4 : 16) != 0) return false; // tile tasks walk K in steps of 16; x is zero-padded
-    if (a.B > 65536 || a.node_cap > 65536) return false; // (agent, node) are packed 16 + 16 bits in the argmin log
+            if (ev.dims[l] % (l == 0 ? 4 : 16) != 0) { // tile tasks walk K in steps of 16; x is zero-padded
+                *why = "asynchronous step: hidden widths must be multiples of 16 and the input width a multiple of 4";
+                return false;
+            }
+    if (a.B > 65536 || a.node_cap > 65536) { // (agent, node) are packed 16 + 16 bits in the argmin log
+        *why = "asynchronous step: more than 65536 agents or nodes per tree";
+        return false;
+    }
     size_t stride = (dyn_lds_bytes(a.n) + 15) & ~(size_t)15;
     if (ev.kind == 3) { // a waiting agent's region holds its row's activations: [x][h0][h1] + the 16-B-per-wave skew
-        size_t rows = ((size_t)((ev.dims[0] + 15) & ~15) + 2 * (size_t)ev.max_hidden) * sizeof(float) + 16 * PERSIST_WAVES;
+        size_t rows = ((size_t)((ev.dims[0] + 15) & ~15) + (size_t)ev.hid[0] + (size_t)ev.hid[1]) * sizeof(float) + 16 * PERSIST_WAVES;
         if (rows > stride) stride = (rows + 15) & ~(size_t)15;
     }
     size_t total = stride * PERSIST_WAVES;
     const size_t static_lds = PERSIST_WAVES * (sizeof(WaveLds) + 16) + sizeof(AsyncCtl) + 256;
-    if (total + static_lds > 160 * 1024) return false;
+    if (total + static_lds > 160 * 1024) {
+        *why = "asynchronous step: 16 rows of activations do not fit the CU's 160 KB of LDS";
+        return false;
+    }
     *dyn_stride = (uint32_t)stride;
     *dyn_bytes = total;
     return true;
@@ -168,31 +176,39 @@ void launch_observe(const Arenas &a, uint32_t n_obs_tol, void *stream) {
 template <class SP>
 static void l_persist(const Arenas &a, const PersistArgs *d_args, int n_calls, unsigned long long *log_key,
                       uint32_t *log_node, uint32_t dyn_stride, size_t dyn_bytes, hipStream_t st) {
-    // dynamic LDS beyond the default limit needs the attribute; ask for what this launch uses (a request
-    // that cannot fit beside the kernel's static LDS fails and the error would stick to the stream)
-    static size_t attr_bytes = 0;
-    if (dyn_bytes > attr_bytes) {
-        if (hipFuncSetAttribute((const void *)k_persist<SP>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn_bytes) == hipSuccess) attr_bytes = dyn_bytes;
-        else (void)hipGetLastError();
-    }
+    // dynamic LDS beyond the default 64 KB needs the attribute, which is per DEVICE (the current one): set on every
+    // launch -- a host-side call, once per <= 1024 search calls -- so that engines on several devices in one process
+    // all get it; the plans have already checked that the request fits beside the kernel's static LDS
+    if (hipFuncSetAttribute((const void *)k_persist<SP>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn_bytes) != hipSuccess) return; // sticky: the caller's hipGetLastError reports it
     const int n_wg = (a.B + PERSIST_WAVES - 1) / PERSIST_WAVES;
     k_persist<SP><<<dim3(n_wg), dim3(PERSIST_WAVES * 64), dyn_bytes, st>>>(d_args, n_calls, log_key, log_node, dyn_stride);
     k_argmin_log<SP><<<dim3(1), dim3(64), SP::dyn_bytes(a), st>>>(a, n_calls, n_wg, log_key, log_node);
 }
 // LDS plan of the persistent step; returns false when the workgroup does not fit a CU
-bool persist_plan(const Arenas &a, const FusedEval &ev, uint32_t *dyn_stride, size_t *dyn_bytes) {
+bool persist_plan(const Arenas &a, const FusedEval &ev, uint32_t *dyn_stride, size_t *dyn_bytes, const char **why) {
+    const char *dummy;
+    if (!why) why = &dummy;
     size_t stride = (dyn_lds_bytes(a.n) + 15) & ~(size_t)15;
     size_t total = stride * PERSIST_WAVES;
-    if (a.space == SPACE_RAMSEY) return ramsey_persist_plan(a, ev, dyn_stride, dyn_bytes);
+    if (a.space == SPACE_RAMSEY) return ramsey_persist_plan(a, ev, dyn_stride, dyn_bytes, why);
     if (ev.kind == 3) {
-        if (ev.bf16) return false; // bf16 weight storage is built into the asynchronous step only
+        if (ev.bf16) { // bf16 weight storage is built into the asynchronous step only
+            *why = "barrier step: bf16 weight storage is not built into it";
+            return false;
+        }
         for (int l = 0; l < ev.n_layers; ++l)
-            if (ev.dims[l] % 4 != 0) return false; // the in-kernel MLP loads rows as float4
-        size_t mlp = (size_t)PERSIST_WAVES * ((size_t)(ev.dims[0] + 4) + 2 * (size_t)(ev.max_hidden + 4)) * sizeof(float);
+            if (ev.dims[l] % 4 != 0) { // the in-kernel MLP loads rows as float4
+                *why = "barrier step: layer widths must be multiples of 4";
+                return false;
+            }
+        size_t mlp = (size_t)PERSIST_WAVES * ((size_t)(ev.dims[0] + 4) + (size_t)(ev.hid[0] + 4) + (size_t)(ev.hid[1] + 4)) * sizeof(float);
         if (mlp > total) total = mlp;
     }
     const size_t static_lds = PERSIST_WAVES * (sizeof(WaveLds) + 16) + 256;
-    if (total + static_lds > 160 * 1024) return false;
+    if (total + static_lds > 160 * 1024) {
+        *why = "barrier step: 16 rows of activations do not fit the CU's 160 KB of LDS";
+        return false;
+    }
     *dyn_stride = (uint32_t)stride;
     *dyn_bytes = total;
     return true;

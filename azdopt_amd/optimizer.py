@@ -105,6 +105,14 @@ class NablaOptimizer:
         _lib.check(self._L.azd_engine_par_update_model(self._h, n_obs_tol, C.byref(loss)), "par_update_model")
         return loss.value
 
+    def par_update_model_sharded(self, n_obs_tol, nccl_comm):
+        """par_update_model over the pooled rows of all ranks of an ncclComm_t (raw handle, e.g. from a C host or
+        ctypes): all-gather of the training triple on the engine's stream + the identical optimiser step"""
+        loss = C.c_float()
+        _lib.check(self._L.azd_engine_par_update_model_sharded(self._h, n_obs_tol, nccl_comm, C.byref(loss)),
+                   "par_update_model_sharded")
+        return loss.value
+
     def par_reset_trees(self, modify_root):
         """optimizer/mod.rs:284-360.  `modify_root` is packed new roots or a callable(optimizer)
         returning them (e.g. lambda o: o.c21_modify_roots(seed, epoch))."""
@@ -258,3 +266,12 @@ class NablaOptimizer:
 
     def stream(self):
         return self._L.azd_engine_stream(self._h)
+
+    STEP_FORMS = {0: "none", 1: "async", 2: "barrier", 3: "per_call"}
+
+    def step_form(self):
+        """(form, reason) of the last par_roll_out_episodes: "async" / "barrier" (CU-resident) or "per_call"
+        (one launch per phase), and why a faster form was not taken"""
+        form, why = C.c_int32(), C.c_char_p()
+        _lib.check(self._L.azd_engine_step_form(self._h, C.byref(form), C.byref(why)), "step_form")
+        return self.STEP_FORMS.get(form.value, "?"), (why.value or b"").decode()

@@ -8,11 +8,19 @@ workgroup's evaluator on the matrix cores; --barrier-step selects the lock-step 
 EPOCH_CALLS steps the epoch boundary of the reference driver (04-c21-tree.rs:163-207:
 par_update_model, modify_root policy, par_reset_trees) runs INSIDE the timed region.
 
-Workload (BASELINE.json configs[1]): c21 space N = 19 (STATE 304, ACTION 152), 4096 agents per GPU,
-fp32 MLP 304-256-256-256-152 (ReLU x3, Sigmoid), n_as_tol = [200, 50, 50] / 25, n_obs_tol = 200,
-800 calls per epoch, seeded synthetic roots.  N > 1: agents shard by global id (weak scaling,
-4096 per GPU, no data-path collective); the training triple is all-gathered over RCCL once per epoch
-so that every rank takes the identical optimiser step.
+Default workload (BASELINE.json configs[1] = --config B): c21 space N = 19 (STATE 304, ACTION 152), 4096 agents
+per GPU, fp32 MLP 304-256-256-256-152 (ReLU x3, Sigmoid), n_as_tol = [200, 50, 50] / 25, n_obs_tol = 200,
+800 calls per epoch, seeded synthetic roots.  --config A / C / D select the other BASELINE configs that are
+built (A: the reference's own run shape, B = 512 with the 512-1024-512 MLP; C: 8192 agents per GPU, bf16
+evaluator storage; D: the Ramsey space, 8192 agents per GPU).  N > 1: agents shard by global id (weak
+scaling, no data-path collective); the training triple is all-gathered over RCCL once per epoch so that
+every rank takes the identical optimiser step (azdopt_amd.parallel.ShardedOptimizer).
+
+What the timed window holds is reported, not assumed: `config.workload` is built from what ran, and
+`epoch_boundaries_in_timed_region` counts the par_update_model + root policy + par_reset_trees sequences
+inside it.  A window shorter than an epoch (the driver's --steps 20) is placed in the MIDDLE of the second
+epoch -- after one whole untimed epoch including its optimiser step, on trees of half-epoch size -- instead of
+on the freshly reset trees of call 0, and says so.
 """
 import argparse
 import json
@@ -25,7 +33,6 @@ sys.path.insert(0, ROOT)
 
 import numpy as np  # noqa: E402
 
-HIDDEN = (256, 256, 256)
 N_OBS_TOL = 200
 EPOCH_CALLS = 800
 SEED = 0
@@ -34,21 +41,24 @@ SEED = 0
 # they keep the drivers' n_as_tol tables (01-r333.rs:128-130, 02-r44.rs:128-130) and use 800-call epochs
 # like c21 (the drivers run 6400 / 3200) so that the arenas stay under 20 GB.
 WORKLOADS = {
-    "c21": dict(kind="c21", n=19, agents=4096, tol=([200, 50, 50], 25), caps={}, name="c21 N=19"),
-    "r333": dict(kind="ramsey", n=16, sizes=[3, 3, 3], agents=8192,
+    "c21": dict(kind="c21", n=19, agents=4096, hidden=(256, 256, 256), tol=([200, 50, 50], 25), caps={}, name="c21 N=19"),
+    # the reference's own run (04-c21-tree.rs:33-54): B = 512, MLP 304-512-1024-512-152
+    "c21ref": dict(kind="c21", n=19, agents=512, hidden=(512, 1024, 512), tol=([200, 50, 50], 25), caps={}, name="c21 N=19"),
+    "r333": dict(kind="ramsey", n=16, sizes=[3, 3, 3], agents=8192, hidden=(256, 256, 256),
                  tol=([200, 200, 200, 100, 100, 100, 50, 50, 50, 25, 25, 25], 10),
                  caps=dict(prediction_capacity=98304), name="Ramsey R(3,3,3) N=16"),
-    "r44": dict(kind="ramsey", n=17, sizes=[4, 4], agents=8192, tol=([200, 200, 100, 100, 50, 50, 25, 25], 10),
+    "r44": dict(kind="ramsey", n=17, sizes=[4, 4], agents=8192, hidden=(256, 256, 256),
+                tol=([200, 200, 100, 100, 50, 50, 25, 25], 10),
                 caps=dict(prediction_capacity=57344), name="Ramsey R(4,4) N=17"),
 }
+# BASELINE.json configs[0..3] as presets: (workload, agents per GPU, evaluator storage)
+CONFIGS = {
+    "A": ("c21ref", 512, "f32"),   # configs[0]: the reference's plumbing shape (its BATCH is 512; "64" is a plot title)
+    "B": ("c21", 4096, "f32"),     # configs[1]: the metric's configuration on one GPU
+    "C": ("c21", 8192, "bf16"),    # configs[2]: 65536 agents over 8 GPUs, bf16 MLP, RCCL all-gather
+    "D": ("r44", 8192, "f32"),     # configs[3]: 32768 agents over 4 GPUs, Ramsey space
+}
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
-
-
-class _DevView:
-    """zero-copy torch view of an engine-owned device buffer (via __cuda_array_interface__)"""
-
-    def __init__(self, ptr, shape):
-        self.__cuda_array_interface__ = dict(shape=tuple(shape), typestr="<f4", data=(int(ptr), False), version=2)
 
 
 def make_space(az, wl):
@@ -79,30 +89,53 @@ def algorithmic_bytes(c0, c1, state_dim, action_dim=None, state_bytes=0):
     return total / exp, d
 
 
-def cpu_baseline(n_threads, steps, wl, krange):
-    """CPU restatement of the reference algorithm (oracle, OpenMP over agents like rayon's par_iter;
-    CPU fp32 MLP) on a bounded sample of the same workload: the first `steps` calls."""
-    from oracle import orc
-    B, n, TOL = wl["agents"], wl["n"], wl["tol"]
+def _cpu_run(orc, wl, hidden, B, n_threads, krange, max_calls, budget_s, with_mlp):
+    """first calls of the workload on the CPU restatement at population B; returns (expansions/s, calls, seconds).
+    Only the restatement's own work is timed (tree phases, and the MLP forward when with_mlp): generating the
+    fixed prediction stream of the tree-only run is not."""
+    n, TOL = wl["n"], wl["tol"]
     if wl["kind"] == "ramsey":
         e = orc.Engine(n, B, threads=n_threads, ramsey=(wl["sizes"], [1.0] * len(wl["sizes"])))
         parents, permitted = orc.gen_ramsey_roots(SEED, 0, 0, B, n, len(wl["sizes"]), *krange)
     else:
         e = orc.Engine(n, B, threads=n_threads)
         parents, permitted = orc.gen_roots(SEED, 0, 0, B, n, *krange)
-    dims = (e.S,) + HIDDEN + (e.A,)
-    mlp = orc.Mlp(dims, seed=SEED, threads=n_threads)
+    mlp = orc.Mlp((e.S,) + tuple(hidden) + (e.A,), seed=SEED, threads=n_threads) if with_mlp else None
     e.new_begin(parents, permitted)
-    e.new_end(mlp.forward(e.state_vecs()))
-    t0 = time.perf_counter()
-    for _ in range(steps):
+    e.new_end(mlp.forward_fast(e.state_vecs()) if with_mlp else orc.hash_predictions(SEED, 0, B, e.A, 0))
+    busy, calls = 0.0, 0
+    while calls < max_calls and busy < budget_s:
+        t0 = time.perf_counter()
         e.rollout_begin(*TOL)
-        e.rollout_end(mlp.forward(e.state_vecs()))
-    dt = time.perf_counter() - t0
-    exp = e.counters()["EXPANSIONS"]
-    return dict(value=exp / dt, unit="expansions/s", cores=n_threads, kind="port",
-                sample=f"first {steps} calls of the same workload (B={B}, N={n}, MLP on CPU), {dt:.1f} s; "
-                       "CPU restatement of the reference algorithm, not the Rust binary (cannot be built here)")
+        t1 = time.perf_counter()
+        h = mlp.forward_fast(e.state_vecs()) if with_mlp else orc.hash_predictions(SEED, 0, B, e.A, calls + 1)
+        t2 = time.perf_counter()
+        e.rollout_end(h)
+        t3 = time.perf_counter()
+        busy += (t3 - t0) if with_mlp else (t1 - t0) + (t3 - t2)  # the model call is part of the end-to-end time only
+        calls += 1
+    return e.counters()["EXPANSIONS"] / busy, calls, busy
+
+
+def cpu_baseline(n_threads, wl, hidden, krange, budget_s=24.0):
+    """CPU restatement of the reference algorithm (oracle; OpenMP over agents = rayon's par_iter, barrier,
+    model call, barrier: optimizer/mod.rs:159-189) on bounded samples of the same workload, BASELINE.md 3:
+    tree-only (fixed prediction stream) and end-to-end (blocked AVX2 fp32 MLP on the host cores) at
+    B = 64, 512 and the GPU run's population."""
+    from oracle import orc
+    pops = sorted({64, 512, wl["agents"]})
+    per = budget_s / (2 * len(pops))
+    rows = {"tree_only": {}, "end_to_end": {}}
+    for B in pops:
+        for key, with_mlp in (("tree_only", False), ("end_to_end", True)):
+            rate, calls, sec = _cpu_run(orc, wl, hidden, B, n_threads, krange, 800, per, with_mlp)
+            rows[key][str(B)] = dict(value=rate, unit="expansions/s", agents=B, calls=calls, seconds=round(sec, 2))
+    top = rows["end_to_end"][str(wl["agents"])]
+    return dict(value=top["value"], unit="expansions/s", cores=n_threads, kind="port",
+                sample="first %d calls of the same workload (B=%d, N=%d, fp32 MLP %s on the CPU, blocked AVX2 loop nest), %.1f s; "
+                       "CPU restatement of the reference algorithm, not the Rust binary (cannot be built here)"
+                       % (top["calls"], wl["agents"], wl["n"], "-".join(map(str, hidden)), top["seconds"]),
+                tree_only=rows["tree_only"], end_to_end=rows["end_to_end"])
 
 
 def main():
@@ -110,26 +143,33 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=1600)
     ap.add_argument("--warmup", type=int, default=800)
-    ap.add_argument("--cpu-steps", type=int, default=200)
+    ap.add_argument("--cpu-seconds", type=float, default=24.0, help="CPU time budget of the cpu_baseline leg")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--chunk", type=int, default=800, help="calls per host round trip (<= one epoch)")
     ap.add_argument("--barrier-step", action="store_true", help="lock-step form (k_persist) instead of the default asynchronous step (k_async)")
-    ap.add_argument("--workload", choices=sorted(WORKLOADS), default="c21")
+    ap.add_argument("--config", choices=sorted(CONFIGS), default=None,
+                    help="BASELINE.json preset: A reference shape (512 agents, 512-1024-512 MLP), B 4096 agents fp32 (default), "
+                         "C 8192 agents/GPU bf16 (65536 at --gpus 8), D Ramsey r44 8192 agents/GPU")
+    ap.add_argument("--workload", choices=sorted(WORKLOADS), default=None)
     ap.add_argument("--agents", type=int, default=0, help="agents per GPU (default: the workload's)")
-    ap.add_argument("--mlp-dtype", choices=["f32", "bf16"], default="f32",
+    ap.add_argument("--mlp-dtype", choices=["f32", "bf16"], default=None,
                     help="evaluator weight/activation storage for inference (bf16 = BASELINE configs[2]; f32 accumulate either way)")
     args = ap.parse_args()
-    wl = dict(WORKLOADS[args.workload])
-    if args.agents > 0:
-        wl["agents"] = args.agents
-    AGENTS_PER_GPU, TOL = wl["agents"], wl["tol"]
+    wl_name, agents, dtype = CONFIGS[args.config or "B"]
+    if args.workload:
+        wl_name = args.workload
+        agents = WORKLOADS[wl_name]["agents"]
+    wl = dict(WORKLOADS[wl_name])
+    wl["agents"] = args.agents if args.agents > 0 else agents
+    mlp_dtype = args.mlp_dtype or dtype
+    AGENTS_PER_GPU, TOL, HIDDEN = wl["agents"], wl["tol"], tuple(wl["hidden"])
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N")
+        raise SystemExit("--gpus %d but WORLD_SIZE is %d: launch with torch.distributed.run --nproc-per-node %d"
+                         % (args.gpus, world, args.gpus))
     import torch
     import torch.distributed as dist
     # rehearsal on a one-GPU box (never used by the driver): AZD_BENCH_REHEARSE=1 puts every rank on
@@ -144,20 +184,19 @@ def main():
             dist.init_process_group("gloo", rank=rank, world_size=world)
         else:
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
-    coll_dev = "cpu" if rehearse else f"cuda:{local_rank}"
 
     import azdopt_amd as az
-    from azdopt_amd.parallel import ShardPlan, allgather_training_triple, global_argmin
+    from azdopt_amd.parallel import ShardedOptimizer
 
-    plan = ShardPlan(world, rank, AGENTS_PER_GPU)
     space = make_space(az, wl)
-    B = plan.local_agents
-    B_total = plan.total_agents
-    model = az.ActionModel(B_total, space.STATE_DIM, space.ACTION_DIM, hidden=HIDDEN, seed=SEED, device=local_rank,
-                           dtype=args.mlp_dtype)
-    roots = space.generate_roots(SEED, B, first_agent=plan.first_agent)
-    opt = az.NablaOptimizer.par_new(space, roots, model, B, device=local_rank, first_agent=plan.first_agent,
-                                    async_step=not args.barrier_step, **wl["caps"])
+    sopt = ShardedOptimizer.par_new(
+        space, lambda total: az.ActionModel(total, space.STATE_DIM, space.ACTION_DIM, hidden=HIDDEN, seed=SEED,
+                                            device=local_rank, dtype=mlp_dtype),
+        AGENTS_PER_GPU, dist=dist if world > 1 else None, torch=torch, seed=SEED, device_index=local_rank, rank=rank,
+        world_size=world, stage_on_cpu=rehearse, async_step=not args.barrier_step, **wl["caps"])
+    opt = sopt.shard.opt  # this rank's NablaOptimizer (counters, timing)
+    B, B_total = sopt.plan.local_agents, sopt.plan.total_agents
+    coll_dev = sopt.coll_device
 
     def barrier():
         if world > 1:
@@ -167,39 +206,37 @@ def main():
     calls_done = 0
     epoch = 0
     losses = []
+    boundaries = 0
 
     def epoch_boundary():
-        nonlocal epoch
-        if world == 1:
-            losses.append(opt.par_update_model(N_OBS_TOL))
-        else:
-            ptrs = opt.observe_dev(N_OBS_TOL)
-            views = [torch.as_tensor(_DevView(p, (B, d)), device=f"cuda:{local_rank}")
-                     for p, d in zip(ptrs, (space.STATE_DIM, space.ACTION_DIM, space.ACTION_DIM))]
-            if rehearse:
-                gathered = [g.cuda() for g in allgather_training_triple(dist, torch, [v.cpu() for v in views], world)]
-            else:
-                # the collective runs on torch-owned copies (20 MB per rank), not on the engine's own allocations
-                gathered = allgather_training_triple(dist, torch, [v.clone() for v in views], world)
-            torch.cuda.synchronize()
-            losses.append(model.update_model_dev(B_total, *[g.data_ptr() for g in gathered], stream=opt.stream()))
-        opt.par_reset_trees_policy(SEED, epoch)  # modify_root policy + reset on the device
+        nonlocal epoch, boundaries
+        losses.append(sopt.par_update_model(N_OBS_TOL))  # N > 1: all-gather of the training triple, then the identical step
+        sopt.par_reset_trees_policy(SEED, epoch)         # modify_root policy + reset on the device
         epoch += 1
+        boundaries += 1
 
     def run(n_calls):
         nonlocal calls_done
         left = n_calls
         while left > 0:
             k = min(left, args.chunk, EPOCH_CALLS - calls_done % EPOCH_CALLS)
-            opt.par_roll_out_episodes(TOL, n_calls=k)
+            sopt.par_roll_out_episodes(TOL, n_calls=k)
             calls_done += k
             left -= k
             if calls_done % EPOCH_CALLS == 0:
                 epoch_boundary()
 
+    # A window shorter than an epoch would otherwise sit on the freshly reset trees of call 0 and before the
+    # first optimiser step: run one whole epoch (untimed, boundary included) and centre the window in the next
+    placed = None
+    if args.steps < EPOCH_CALLS and args.warmup + args.steps <= EPOCH_CALLS // 2:
+        lead = EPOCH_CALLS + EPOCH_CALLS // 2 - args.steps // 2 - args.warmup
+        run(lead)
+        placed = (calls_done + args.warmup) % EPOCH_CALLS
     run(args.warmup)
     opt.set_timing(True)
     c0 = opt.counters()
+    b0 = boundaries
     barrier()
     t0 = time.perf_counter()
     run(args.steps)
@@ -208,6 +245,10 @@ def main():
     c1 = opt.counters()
     timing = opt.timing()
     opt.set_timing(False)
+    n_bound = boundaries - b0
+    form, form_why = opt.step_form()
+    if c1["FAILED"] != 0:
+        raise SystemExit("bench: %d agents stopped on a full arena; the rate would count fewer working agents" % c1["FAILED"])
 
     exp_local = c1["EXPANSIONS"] - c0["EXPANSIONS"]
     if world > 1:
@@ -218,44 +259,58 @@ def main():
         dt_max, exp_total = float(tmax[0]), float(t[1])
     else:
         dt_max, exp_total = dt, float(exp_local)
-    am = opt.argmin_data()
-    cost = float(sum(am.cost["clique_counts"])) if wl["kind"] == "ramsey" else am.cost["lambda_1"] + len(am.cost["matching"])
-    best_eval, best_cost = global_argmin(dist if world > 1 else None, torch, float(am.eval), cost, local_rank, device=coll_dev)
+    best_eval, best_cost = sopt.global_argmin()
 
     if rank == 0:
         state_bytes = (space.C * space.E * 4 + 512) if wl["kind"] == "ramsey" else 0
         bytes_per_exp, d = algorithmic_bytes(c0, c1, space.STATE_DIM, space.ACTION_DIM, state_bytes)
         kw = space.KEY_WORDS
-        use_async = not args.barrier_step
         dims_txt = "-".join(str(x) for x in (space.STATE_DIM,) + HIDDEN + (space.ACTION_DIM,))
         launches = max(1, timing["rollout_launches"])
         avg_ms = timing["rollout_ms"] / launches
         bytes_per_launch = bytes_per_exp * exp_local / launches
         achieved = bytes_per_launch / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
-        traffic = None
+        kernel = {"async": "k_async<%d>", "barrier": "k_persist<%d>", "per_call": "k_rollout<%d>"}.get(form, "?<%d>") % kw
+        # HBM traffic is not measured by this process (PMC counters need rocprofv3): it is the per-call figure of the
+        # committed profile of the same kernel and workload, scaled to this run's calls per launch, or null
+        traffic, traffic_src = None, None
         tpath = os.path.join(ROOT, "profiles", "traffic.json")
-        if os.path.exists(tpath) and args.workload == "c21":
+        if os.path.exists(tpath) and wl_name == "c21" and AGENTS_PER_GPU == 4096 and mlp_dtype == "f32" and form in ("async", "barrier"):
             try:
-                per_call = json.load(open(tpath)).get("k_async_hbm_bytes_per_call" if use_async else "k_persist_hbm_bytes_per_call")
-                traffic = per_call * args.steps / launches if per_call else None  # PMC bytes per call x calls per launch
+                tj = json.load(open(tpath))
+                per_call = tj.get("k_async_hbm_bytes_per_call" if form == "async" else "k_persist_hbm_bytes_per_call")
+                if per_call:
+                    traffic = per_call * args.steps / launches
+                    traffic_src = "profiles/traffic.json (rocprofv3 --pmc TCC counters of %s, 800-call launches: %s) x %.0f calls per launch; not measured in this run" \
+                                  % (kernel, tj.get("source", "see profiles/README.md"), args.steps / launches)
             except Exception:
                 traffic = None
+        if n_bound:
+            window = "%d calls incl. %d epoch boundar%s (par_update_model + root policy + par_reset_trees; %d calls/epoch)" \
+                     % (args.steps, n_bound, "y" if n_bound == 1 else "ies", EPOCH_CALLS)
+        elif placed is not None:
+            window = "%d calls from call %d of the second %d-call epoch (one untimed epoch incl. its optimiser step before; " \
+                     "no epoch boundary inside the window)" % (args.steps, placed, EPOCH_CALLS)
+        else:
+            window = "%d calls, no epoch boundary inside the window (%d calls/epoch)" % (args.steps, EPOCH_CALLS)
         out = {
             "metric": "node_expansions_per_s", "value": exp_total / dt_max, "unit": "expansions/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * dt_max / args.steps,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.mlp_dtype, "data": "synthetic",
-            "config": {"workload": "%s tree search, %d agents/GPU, %s MLP %s, tol %s/%d, "
-                                   "800 calls/epoch incl. update_model+reset_trees"
-                                   % (wl["name"], AGENTS_PER_GPU, "fp32" if args.mlp_dtype == "f32" else "bf16-storage", dims_txt,
-                                      str(TOL[0]).replace(" ", ""), TOL[1]),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": mlp_dtype, "data": "synthetic",
+            "config": {"workload": "%s tree search, %d agents/GPU, %s MLP %s, tol %s/%d; timed: %s"
+                                   % (wl["name"], AGENTS_PER_GPU, "fp32" if mlp_dtype == "f32" else "bf16-storage", dims_txt,
+                                      str(TOL[0]).replace(" ", ""), TOL[1], window),
+                       "baseline_config": args.config or ("B" if (wl_name, AGENTS_PER_GPU, mlp_dtype) == CONFIGS["B"] else None),
                        "agents_total": B_total, "parallelism": f"agents sharded x{world}"},
+            "step_form": form, "step_form_reason": form_why,
+            "epoch_boundary_in_timed_region": n_bound > 0, "epoch_boundaries_in_timed_region": n_bound,
             "best_cost_found": best_cost, "best_eval": best_eval,
             "expansions": exp_total, "terminals": d["TERMINALS"], "transpositions": d["TRANSPOSITIONS"],
             "select_calls_per_expansion": d["SELECT_CALLS"] / max(1, d["EXPANSIONS"]),
             "epoch_losses": losses[-3:],
             "calls_per_launch": args.steps / launches,
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "kernel": ("k_async<%d>" if use_async else "k_persist<%d>") % kw,
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src, "kernel": kernel,
                          "algorithmic_bytes_per_expansion": bytes_per_exp, "avg_launch_ms": avg_ms,
                          "mlp_flop_per_launch": 2.0 * sum(a * b for a, b in zip((space.STATE_DIM,) + HIDDEN, HIDDEN + (space.ACTION_DIM,)))
                                                 * ((B + 15) // 16 * 16) * args.steps / launches,
@@ -263,7 +318,7 @@ def main():
                                  "~3 orders of magnitude apart for this workload (SURVEY.md 8d)"},
         }
         if not args.no_cpu_baseline and world == 1:  # timed beside the GPU run at N = 1 only
-            out["cpu_baseline"] = cpu_baseline(min(os.cpu_count() or 1, 64), args.cpu_steps, wl, space.default_permitted_range())
+            out["cpu_baseline"] = cpu_baseline(min(os.cpu_count() or 1, 64), wl, HIDDEN, space.default_permitted_range(), args.cpu_seconds)
         else:
             out["cpu_baseline"] = None
         print(json.dumps(out), flush=True)

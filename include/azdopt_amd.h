@@ -270,6 +270,14 @@ int azd_engine_par_roll_out_episodes(azd_engine *e, const uint32_t *n_as_tol, in
                                      uint32_t n_as_tol_default, int n_calls, int *improved);
 /* NablaOptimizer::par_update_model (optimizer/mod.rs:249-281) */
 int azd_engine_par_update_model(azd_engine *e, uint32_t n_obs_tol, float *loss);
+/* par_update_model for a population SHARDED over several GPUs (one engine per process and GPU, contiguous agent
+ * ranges in rank order; the reference has no such form -- optimizer/mod.rs:249-281 on one device): the training
+ * triple of this rank (optimizer/mod.rs:262-278) is all-gathered over RCCL on the engine's stream into
+ * engine-owned buffers, then every rank takes the identical optimiser step on the pooled batch*world rows (the
+ * loss normaliser sum(w) is global over the batch, model/dfdx.rs:106,110).  `nccl_comm` is the caller's ncclComm_t
+ * (ncclCommInitRank on this engine's device); the evaluator must have been created with max_batch >= batch*world.
+ * librccl.so is bound at first use; AZD_ERR_UNSUPPORTED if it cannot be loaded. */
+int azd_engine_par_update_model_sharded(azd_engine *e, uint32_t n_obs_tol, void *nccl_comm, float *loss);
 /* NablaOptimizer::par_reset_trees (optimizer/mod.rs:284-360) with the
  * `modify_root` closure applied by the caller (see azd_c21_modify_roots). */
 int azd_engine_par_reset_trees(azd_engine *e, const uint8_t *parents, const uint64_t *permitted);
@@ -335,6 +343,15 @@ int azd_engine_agent_counters(azd_engine *e, uint64_t *out);
 int azd_engine_set_timing(azd_engine *e, int enabled);
 int azd_engine_timing(azd_engine *e, double *tree_ms, double *evaluator_ms, uint64_t *tree_launches);
 void *azd_engine_stream(azd_engine *e); /* hipStream_t the engine launches on */
+/* Which form of the step the last azd_engine_par_roll_out_episodes ran (identical results, very different
+ * speed): the asynchronous CU-resident step, the lock-step CU-resident step, or one launch per phase and
+ * call (external evaluators, models the in-kernel evaluator cannot take).  *reason (owned by the engine,
+ * valid until the next call) says why a faster form was not taken, "" for AZD_STEP_ASYNC. */
+#define AZD_STEP_NONE 0
+#define AZD_STEP_ASYNC 1
+#define AZD_STEP_BARRIER 2
+#define AZD_STEP_PER_CALL 3
+int azd_engine_step_form(azd_engine *e, int *form, const char **reason);
 
 /* Parity probe for the two f32 primitives the selection rule (tree/next_action.rs:70,81) depends
  * on bit-for-bit.  in: 2*n floats (pairs x, y); out: 4*n floats per pair:

@@ -1380,6 +1380,74 @@ static void layer_forward(const orc_mlp *m, int l, int batch, const float *x, fl
     }
 }
 
+/* The same layer, blocked and vectorised for the CPU-baseline timing (bench.py cpu_baseline): 16 rows at a
+ * time, transposed so that one 8-float vector holds one input feature of 8 rows, 4 output neurons per pass.
+ * Every output element is still the sum over i = 0..in-1 in order of separately rounded products plus the
+ * bias (no FMA, no reassociation), so the result equals layer_forward's bit for bit (tests/test_oracle_mlp_fast.py). */
+typedef float v8f __attribute__((vector_size(32)));
+typedef float v8fu __attribute__((vector_size(32), aligned(4)));
+__attribute__((target("avx2"))) static void layer_forward_blocked(const orc_mlp *m, int l, int batch, const float *x, float *y) {
+    const int in = m->dims[l], out = m->dims[l + 1];
+    const int act = (l == m->L - 1) ? m->final_act : 1;
+    const float *W = m->W[l].data(), *bb = m->b[l].data();
+    const int n_blocks = (batch + 15) / 16;
+#pragma omp parallel num_threads(m->threads)
+    {
+        std::vector<float> xT((size_t)in * 16);
+#pragma omp for schedule(static)
+        for (int blk = 0; blk < n_blocks; ++blk) {
+            const int rb = blk * 16, nr = batch - rb < 16 ? batch - rb : 16;
+            for (int r = 0; r < 16; ++r)
+                for (int i = 0; i < in; ++i) xT[(size_t)i * 16 + r] = r < nr ? x[(size_t)(rb + r) * in + i] : 0.f;
+            for (int o = 0; o < out; o += 4) {
+                const int no = out - o < 4 ? out - o : 4;
+                const float *w0 = W + (size_t)o * in, *w1 = W + (size_t)(o + (no > 1 ? 1 : 0)) * in;
+                const float *w2 = W + (size_t)(o + (no > 2 ? 2 : 0)) * in, *w3 = W + (size_t)(o + (no > 3 ? 3 : 0)) * in;
+                v8f a00 = {0}, a01 = {0}, a10 = {0}, a11 = {0}, a20 = {0}, a21 = {0}, a30 = {0}, a31 = {0};
+                for (int i = 0; i < in; ++i) {
+                    const v8f x0 = *reinterpret_cast<const v8fu *>(&xT[(size_t)i * 16]);
+                    const v8f x1 = *reinterpret_cast<const v8fu *>(&xT[(size_t)i * 16 + 8]);
+                    const float s0 = w0[i], s1 = w1[i], s2 = w2[i], s3 = w3[i];
+                    a00 += x0 * s0; a01 += x1 * s0;
+                    a10 += x0 * s1; a11 += x1 * s1;
+                    a20 += x0 * s2; a21 += x1 * s2;
+                    a30 += x0 * s3; a31 += x1 * s3;
+                }
+                const v8f acc[4][2] = {{a00, a01}, {a10, a11}, {a20, a21}, {a30, a31}};
+                for (int q = 0; q < no; ++q)
+                    for (int r = 0; r < nr; ++r) {
+                        float s = acc[q][r >> 3][r & 7] + bb[o + q];
+                        if (act == 1) s = s > 0.f ? s : 0.f;
+                        else if (act == 2) s = 1.0f / (1.0f + std::exp(-s));
+                        y[(size_t)(rb + r) * out + o + q] = s;
+                    }
+            }
+        }
+    }
+}
+
+/* model/dfdx.rs:69-84, blocked (see layer_forward_blocked); falls back to orc_mlp_forward without AVX2 */
+int orc_mlp_forward_fast(orc_mlp *m, int batch, const float *states, float *preds) {
+    if (!__builtin_cpu_supports("avx2")) {
+        orc_mlp_forward(m, batch, states, preds);
+        return 0;
+    }
+    std::vector<float> a, bbuf;
+    const float *x = states;
+    for (int l = 0; l < m->L; ++l) {
+        float *y;
+        if (l == m->L - 1) y = preds;
+        else {
+            std::vector<float> &dst = (l & 1) ? bbuf : a;
+            dst.resize((size_t)batch * m->dims[l + 1]);
+            y = dst.data();
+        }
+        layer_forward_blocked(m, l, batch, x, y);
+        x = y;
+    }
+    return 1;
+}
+
 /* model/dfdx.rs:69-84 */
 void orc_mlp_forward(orc_mlp *m, int batch, const float *states, float *preds) {
     std::vector<float> a, bbuf;

@@ -142,6 +142,9 @@ int64_t orc_mlp_num_params(orc_mlp *m);
 void orc_mlp_get_params(orc_mlp *m, float *out); /* per layer: W[out][in] then b[out] */
 void orc_mlp_set_params(orc_mlp *m, const float *in);
 void orc_mlp_forward(orc_mlp *m, int batch, const float *states, float *preds);
+/* the same rows bit for bit from a blocked, AVX2-vectorised loop nest (the CPU-baseline timing uses this one);
+ * returns 1 if the vector path ran, 0 if it fell back to orc_mlp_forward */
+int orc_mlp_forward_fast(orc_mlp *m, int batch, const float *states, float *preds);
 float orc_mlp_update(orc_mlp *m, int batch, const float *states, const float *obs,
                      const float *weights);
 

@@ -1,0 +1,114 @@
+"""GPU tests of the reference's own run shape (graph-state/examples/04-c21-tree.rs:33-54,87-92: B = 512,
+N = 19, MLP 304 -> 512 -> 1024 -> 512 -> 152 fp32) on the CU-resident step, of the step-form report, and
+of the error a full prediction arena must raise in every step form."""
+import numpy as np
+import pytest
+
+from test_gpu_parity import MAIN_CTRS, TOL_REF, assert_tree_equal
+
+pytestmark = pytest.mark.gpu
+
+REF_HIDDEN = (512, 1024, 512)  # 04-c21-tree.rs:46-52
+
+
+@pytest.fixture(scope="module")
+def az():
+    import azdopt_amd
+    assert azdopt_amd.device_count() > 0, "no MI355X visible"
+    return azdopt_amd
+
+
+def test_reference_shape_runs_on_the_async_step_with_oracle_parity(az, orc):
+    """B = 512, N = 19 and the reference's MLP: the engine must take the asynchronous CU-resident step
+    (the two activation buffers of a row are sized 512 / 1024, which fits the CU's LDS), every expansion
+    must get its row from the in-kernel evaluator, and the trees must equal the oracle's bit for bit when
+    the oracle is fed the GPU's prediction rows."""
+    n, B, seed = 19, 512, 3
+    space = az.ROTModifyParentsOnce(n)
+    model = az.ActionModel(B, space.STATE_DIM, space.ACTION_DIM, hidden=REF_HIDDEN, seed=seed)
+    parents, permitted = space.generate_roots(seed, B)
+    opt = az.NablaOptimizer.par_new(space, (parents, permitted), model, B)
+    oe = orc.Engine(n, B, threads=8)
+    oe.new_begin(parents, permitted)
+    oe.new_end(opt.predictions())
+    for s in range(40):
+        opt.par_roll_out_episodes(TOL_REF)
+        assert opt.step_form() == ("async", ""), s
+        oe.rollout_begin(*TOL_REF)
+        assert np.array_equal(opt.state_vecs(), oe.state_vecs())
+        oe.rollout_end(opt.predictions())
+    c = opt.counters()
+    assert c["EXPANSIONS"] > 0 and c["EVAL_ROWS"] == c["EXPANSIONS"]
+    co = oe.counters()
+    for k in MAIN_CTRS:
+        assert c[k] == co[k], k
+    for i in range(0, B, 7):
+        assert_tree_equal(opt.get_tree(i), oe.export_tree(i), f"agent {i}")
+    # the rows themselves: in-kernel evaluator vs the CPU restatement of the MLP on the same states
+    om = orc.Mlp((space.STATE_DIM,) + REF_HIDDEN + (space.ACTION_DIM,), seed=seed, threads=8)
+    om.set_params(model.get_params())
+    sv, pg = opt.state_vecs(), opt.predictions()
+    po = om.forward(sv)
+    live = np.array([opt.agent_state(i)["path"].any() for i in range(0, B, 16)])  # rows of agents with an empty path are stale
+    rows = np.arange(0, B, 16)[live]
+    assert len(rows) > 8 and np.max(np.abs(pg[rows] - po[rows])) < 2e-5
+
+
+def test_reference_shape_many_calls_per_launch_all_forms_agree(az):
+    """One launch of 200 calls with the reference's MLP: asynchronous step == barrier step == launch per
+    phase on counters, argmin and trees (the MFMA k-order per output element is the same in the two
+    CU-resident forms; the launch-per-phase form uses the batched GEMM, so it is compared on a few calls
+    only, before a last-bit difference of a row could change a selection)."""
+    n, B, seed = 19, 512, 5
+    space = az.ROTModifyParentsOnce(n)
+    roots = space.generate_roots(seed, B)
+    runs = []
+    for async_step in (True, False):
+        model = az.ActionModel(B, space.STATE_DIM, space.ACTION_DIM, hidden=REF_HIDDEN, seed=seed)
+        o = az.NablaOptimizer.par_new(space, roots, model, B, async_step=async_step)
+        imp = o.par_roll_out_episodes(TOL_REF, n_calls=200)
+        runs.append((o, imp))
+    assert runs[0][0].step_form()[0] == "async"
+    form, why = runs[1][0].step_form()
+    assert form == "barrier" and "AZD_ENGINE_BARRIER_STEP" in why
+    (o0, i0), (o1, i1) = runs
+    assert i0 == i1
+    c0, c1 = o0.counters(), o1.counters()
+    for k in MAIN_CTRS:
+        assert c0[k] == c1[k], k
+    assert c0["EVAL_ROWS"] == c0["EXPANSIONS"] and c0["FAILED"] == 0
+    a0, a1 = o0.argmin_data(), o1.argmin_data()
+    assert (a0.eval, a0.agent, a0.node) == (a1.eval, a1.agent, a1.node)
+    for i in range(0, B, 31):
+        assert_tree_equal(o0.get_tree(i), o1.get_tree(i), f"agent {i}")
+
+
+def test_step_form_reports_the_fallback_and_its_reason(az):
+    """A model the in-kernel evaluator cannot take (a hidden width that is not a multiple of 4) runs one launch
+    per phase; the engine says so instead of falling back silently."""
+    n, B = 11, 32
+    space = az.ROTModifyParentsOnce(n)
+    roots = space.generate_roots(0, B)
+    model = az.ActionModel(B, space.STATE_DIM, space.ACTION_DIM, hidden=(50, 30), seed=1)
+    o = az.NablaOptimizer.par_new(space, roots, model, B)
+    assert o.step_form()[0] == "none"
+    o.par_roll_out_episodes(TOL_REF, n_calls=2)
+    form, why = o.step_form()
+    assert form == "per_call" and "multiple of 4" in why
+    o2 = az.NablaOptimizer.par_new(space, roots, model, B, persistent=False)
+    o2.par_roll_out_episodes(TOL_REF, n_calls=1)
+    assert o2.step_form() == ("per_call", "AZD_ENGINE_NO_PERSISTENT_STEP")
+
+
+@pytest.mark.parametrize("persistent,async_step", [(True, True), (True, False), (False, False)])
+def test_prediction_capacity_overflow_is_reported(az, persistent, async_step):
+    """A full prediction arena stops the agent (graph_operations.rs:32-56 cannot append) and the call
+    returns AZD_ERR_CAPACITY in every step form, as for the node arena."""
+    space = az.ROTModifyParentsOnce(19)
+    model = az.HashStreamModel(space.STATE_DIM, space.ACTION_DIM, 0)
+    opt = az.NablaOptimizer.par_new(space, space.generate_roots(0, 32), model, 32, prediction_capacity=600,
+                                    persistent=persistent, async_step=async_step)
+    with pytest.raises(az.AzdError) as ei:
+        opt.par_roll_out_episodes(TOL_REF, n_calls=200)
+    assert ei.value.status == 4  # AZD_ERR_CAPACITY
+    assert opt.counters()["FAILED"] > 0

@@ -1,5 +1,7 @@
 """world_size-2 gloo tests of the N > 1 path (CPU): shard plan, shard-invariant root / prediction
-streams, all-gather of the training triple in global agent order, MINLOC argmin."""
+streams, all-gather of the training triple in global agent order, MINLOC argmin, and the ShardedOptimizer class
+end to end (two epochs with the MLP, the pooled optimiser step and the root policy) against ONE optimizer over
+the whole population."""
 import os
 import socket
 import sys
@@ -97,3 +99,118 @@ def test_shard_plan():
     assert p.owner(3 * 8192 + 5) == 3 and p.local_index(3 * 8192 + 5) == 5
     with pytest.raises(ValueError):
         ShardPlan(2, 2, 4)
+
+
+# ---------------------------------------------------------------- ShardedOptimizer end to end
+TOL = ([200, 50, 50], 25)
+DIMS_HIDDEN = (32, 16)
+
+
+class OracleShard:
+    """The local half of a ShardedOptimizer with the CPU oracle standing in for the GPU engine (there is no GPU
+    here): the same methods as azdopt_amd.parallel.EngineShard."""
+    coll_device = "cpu"
+
+    def __init__(self, orc, n, plan, seed, total_rows):
+        from azdopt_amd.space import ROTModifyParentsOnce
+        self.orc, self.plan, self.seed = orc, plan, seed
+        self.space = ROTModifyParentsOnce(n)
+        self.e = orc.Engine(n, plan.local_agents, threads=1)
+        self.mlp = orc.Mlp((self.e.S,) + DIMS_HIDDEN + (self.e.A,), seed=seed, threads=1)
+        self.kr = self.space.default_permitted_range()
+        roots = self.space.generate_roots(seed, plan.local_agents, first_agent=plan.first_agent)
+        self.e.new_begin(*roots)
+        self.e.new_end(self.mlp.forward(self.e.state_vecs()))
+        self.improved = 0
+
+    def roll_out(self, n_as_tol, n_calls):
+        imp = 0
+        for _ in range(n_calls):
+            self.e.rollout_begin(*n_as_tol)
+            imp += self.e.rollout_end(self.mlp.forward(self.e.state_vecs()))
+        return imp
+
+    def triple(self, n_obs_tol):
+        obs, w = self.e.observe(n_obs_tol)
+        return [torch.from_numpy(x.copy()) for x in (self.e.state_vecs(), obs, w)]
+
+    def update_local(self, n_obs_tol):
+        sv, obs, w = [t.numpy() for t in self.triple(n_obs_tol)]
+        return self.mlp.update(sv, obs, w)
+
+    def update_pooled(self, rows, pooled):
+        sv, obs, w = [t.numpy() for t in pooled]
+        assert sv.shape[0] == rows
+        return self.mlp.update(sv, obs, w)
+
+    def reset_policy(self, seed, epoch, kmin=None, kmax=None):
+        roots = self.e.modify_roots(seed, epoch, self.plan.first_agent, *self.kr)
+        self.e.reset_begin(*roots)
+        self.e.reset_end(self.mlp.forward(self.e.state_vecs()))
+
+    def argmin(self):
+        am = self.e.argmin()
+        return float(am["eval"]), am["lambda1"] + am["matching"], am
+
+    def expansions(self):
+        return self.e.counters()["EXPANSIONS"]
+
+
+def _drive(sopt, epochs, calls):
+    """the driver loop of 04-c21-tree.rs:140-208 over a (Sharded)Optimizer"""
+    losses = []
+    for epoch in range(epochs):
+        sopt.par_roll_out_episodes(TOL, n_calls=calls)
+        losses.append(sopt.par_update_model(1))
+        sopt.par_reset_trees_policy(7, epoch)
+    sopt.par_roll_out_episodes(TOL, n_calls=5)
+    return losses
+
+
+def _sharded_worker(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from azdopt_amd.parallel import ShardedOptimizer, ShardPlan
+        from oracle import orc
+        plan = ShardPlan(world, rank, 5)
+        shard = OracleShard(orc, 11, plan, 7, plan.total_agents)
+        sopt = ShardedOptimizer(shard, plan, dist, torch)
+        losses = _drive(sopt, 2, 25)
+        q.put((rank, losses, shard.mlp.get_params(), sopt.global_argmin(), sopt.total_expansions(),
+               shard.e.state_vecs(), float(shard.e.argmin()["eval"])))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_sharded_optimizer_equals_one_optimizer_gloo(orc):
+    """Two ranks x 5 agents through ShardedOptimizer (all-gather of the training triple, pooled optimiser step,
+    per-rank root policy, MINLOC) == one optimizer over the 10 agents: losses, parameters, state vectors, total
+    expansions and the best evaluation, bit for bit."""
+    world = 2
+    port = _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_sharded_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=240) for _ in range(world)], key=lambda x: x[0])
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    from azdopt_amd.parallel import ShardedOptimizer, ShardPlan
+    plan = ShardPlan(1, 0, 10)
+    one = OracleShard(orc, 11, plan, 7, 10)
+    sopt = ShardedOptimizer(one, plan, None, torch)
+    losses = _drive(sopt, 2, 25)
+    params = one.mlp.get_params()
+    for r in res:
+        assert r[1] == losses                                                      # the pooled loss, every epoch
+        assert np.array_equal(r[2].view(np.uint32), params.view(np.uint32))        # replicas in lock-step
+        assert r[3][0] == sopt.global_argmin()[0] and r[4] == sopt.total_expansions()
+    sv = one.e.state_vecs()
+    assert np.array_equal(np.concatenate([res[0][5], res[1][5]]), sv)              # same trees => same current states
+    assert min(res[0][6], res[1][6]) == float(one.e.argmin()["eval"])
+    assert losses[0] > 0 and np.isfinite(losses).all()
