@@ -20,6 +20,7 @@ ACT_NONE, ACT_RELU, ACT_SIGMOID = 0, 1, 2
 ENGINE_NO_PERSISTENT_STEP = 1
 ENGINE_ASYNC_STEP = 2
 ENGINE_BARRIER_STEP = 4
+ENGINE_POOL_STEP = 8
 SPACE_C21 = 1
 SPACE_RAMSEY = 2
 PATH_SET, PATH_SEQUENCE = 0, 1
@@ -142,6 +143,8 @@ def lib():
     sig("azd_engine_timing", C.c_int, vp, C.POINTER(C.c_double), C.POINTER(C.c_double), u64p)
     sig("azd_engine_stream", vp, vp)
     sig("azd_engine_step_form", C.c_int, vp, i32p, C.POINTER(C.c_char_p))
+    sig("azd_engine_pool_split", C.c_int, vp, i32p, i32p)
+    sig("azd_debug_probe_xcc", C.c_int, C.c_int, vp, C.c_int)
     sig("azd_debug_probe_math", C.c_int, C.c_int, vp, vp, C.c_int)
     sig("azd_debug_probe_cost", C.c_int, C.c_int, vp, C.c_int, C.c_int, C.c_int, C.c_int, vp, vp, f32p)
     _LIB = L

@@ -135,6 +135,12 @@ struct azd_engine {
     unsigned long long *d_log_key = nullptr;
     uint32_t *d_log_node = nullptr;
     int log_calls = 0;
+    // pool step (agents multiplexed over searcher waves, evaluator workgroups on CUs of their own)
+    bool pool_step = false;
+    azd::PoolArgs pool{};         // device pointers of the queues
+    size_t pool_slot_words = 0;
+    int n_cus = 0;
+    int pool_eval_wgs = 0, pool_search_wgs = 0; // of the last launch (diagnostics)
     float *d_pool = nullptr;      // pooled training triple of all ranks (azd_engine_par_update_model_sharded)
     size_t pool_rows = 0;
     int step_form = 0;            // AZD_STEP_* chosen by the last par_roll_out_episodes
@@ -550,6 +556,29 @@ int azd_engine_create(azd_engine **out, const azd_engine_config *cfg, azd_evalua
     }
     e->persist_enabled = (cfg->flags & AZD_ENGINE_NO_PERSISTENT_STEP) == 0;
     e->barrier_step = (cfg->flags & AZD_ENGINE_BARRIER_STEP) != 0;
+    // default: the pool step for populations of 256 agents and more (below that a row's trip to an evaluator CU and
+    // back costs more than the asynchronous step's in-workgroup evaluator: 0.36 against 0.49 M expansions/s at 64 agents,
+    // 4.7 against 3.7 at 512); AZD_ENGINE_POOL_STEP / AZD_ENGINE_ASYNC_STEP / AZD_ENGINE_BARRIER_STEP force a form
+    e->pool_step = (cfg->flags & AZD_ENGINE_POOL_STEP) != 0 ||
+                   ((cfg->flags & (AZD_ENGINE_ASYNC_STEP | AZD_ENGINE_BARRIER_STEP)) == 0 && cfg->batch >= 256);
+    if (const char *env = getenv("AZD_STEP_FORM")) { // experiments: override the configured form
+        if (!strcmp(env, "pool")) e->pool_step = true, e->barrier_step = false;
+        else if (!strcmp(env, "async")) e->pool_step = false, e->barrier_step = false;
+        else if (!strcmp(env, "barrier")) e->pool_step = false, e->barrier_step = true;
+    }
+    {
+        hipDeviceProp_t prop;
+        e->n_cus = hipGetDeviceProperties(&prop, cfg->device) == hipSuccess ? prop.multiProcessorCount : 256;
+        uint32_t qcap = 128;
+        while (qcap < 2u * (uint32_t)a.B) qcap <<= 1;
+        e->pool.qcap = qcap;
+        e->pool_slot_words = (size_t)2 * azd::POOL_XCDS * qcap;
+        TRY(e->alloc(&e->pool.ctl, 1));
+        TRY(e->alloc(&e->pool.ready_slots, e->pool_slot_words));
+        e->pool.eval_slots = e->pool.ready_slots + (size_t)azd::POOL_XCDS * qcap;
+        TRY(e->alloc(&e->pool.calls_done, B));
+        TRY(e->alloc(&e->pool.pend, B));
+    }
     e->log_calls = 1024;
     {
         const size_t n_wg = (B + 15) / 16;
@@ -686,20 +715,56 @@ int azd_engine_par_roll_out_episodes(azd_engine *e, const uint32_t *tol, int n_t
     size_t dyn_bytes = 0;
     const bool fusable = e->persist_enabled && e->ev->fused_desc(&fe);
     const char *why_a = "", *why_b = "";
-    const bool use_async = fusable && !e->barrier_step && azd::async_plan(e->a, fe, &dyn_stride, &dyn_bytes, &why_a);
-    const bool use_barrier = fusable && !use_async && azd::persist_plan(e->a, fe, &dyn_stride, &dyn_bytes, &why_b);
+    const char *why_p = "";
+    azd::PoolArgs pool = e->pool;
+    const bool use_pool = fusable && e->pool_step && azd::pool_plan(e->a, fe, &pool, &dyn_stride, &dyn_bytes, &why_p);
+    const bool use_async = fusable && !use_pool && !e->barrier_step && azd::async_plan(e->a, fe, &dyn_stride, &dyn_bytes, &why_a);
+    const bool use_barrier = fusable && !use_pool && !use_async && azd::persist_plan(e->a, fe, &dyn_stride, &dyn_bytes, &why_b);
     // which form runs is part of the result a caller may want to check (azd_engine_step_form): the launch-per-phase
     // form is several times slower than the CU-resident ones
-    e->step_form = use_async ? AZD_STEP_ASYNC : use_barrier ? AZD_STEP_BARRIER : AZD_STEP_PER_CALL;
+    e->step_form = use_pool ? AZD_STEP_POOL : use_async ? AZD_STEP_ASYNC : use_barrier ? AZD_STEP_BARRIER : AZD_STEP_PER_CALL;
     e->step_reason.clear();
-    if (!use_async) {
+    if (e->pool_step && fusable && !use_pool) e->step_reason = std::string(why_p) + "; ";
+    if (!use_async && !use_pool) {
         if (!e->persist_enabled) e->step_reason = "AZD_ENGINE_NO_PERSISTENT_STEP";
         else if (!fusable) e->step_reason = "the evaluator cannot run inside the kernel (external model, more than 7 layers, or a layer width that is not a multiple of 4)";
         else if (e->barrier_step) e->step_reason = "AZD_ENGINE_BARRIER_STEP";
-        else e->step_reason = why_a;
+        else e->step_reason += why_a;
         if (fusable && !use_barrier && *why_b) e->step_reason += std::string("; ") + why_b;
     }
-    if (use_async || use_barrier) {
+    int pool_blocks = 0;
+    if (use_pool) {
+        // Split of the CUs between the two roles, in proportion to the CU time a row costs an evaluator and a call costs
+        // the searchers.  AZD_POOL_EVAL_WGS / AZD_POOL_SEARCH_WGS override (experiments).
+        const int B = e->a.B;
+        int n_eval = 0;
+        if (fe.kind == 3) {
+            double flop = 0;
+            for (int l = 0; l < fe.n_layers; ++l) flop += 2.0 * fe.dims[l] * fe.dims[l + 1];
+            // measured (profiles/r02_pool_probe.txt): a 16-row fp32 batch of the 3 x 256 MLP takes 25 us of an evaluator
+            // CU, bf16 storage 16 us; pure search 4.65 us of a CU per call on young trees.  Whole epochs (older, larger
+            // trees) want a few more evaluators than that ratio says: best 88-100 of 256 at 4096 agents fp32, 80 at 8192,
+            // 56 at 8192 bf16 (gpurun sweeps r2c/sw_*), which the constants below reproduce
+            const double eval_us_per_row = flop / (256.0 * 2400.0) / (fe.bf16 ? 1.85 : 1.0) / 0.33;
+            const double search_us_per_call = 4.65;
+            n_eval = (int)(e->n_cus * eval_us_per_row / (eval_us_per_row + search_us_per_call) + 0.5);
+            const int cap = (B + 15) / 16 + 1;
+            n_eval = n_eval > cap ? cap : n_eval;
+            n_eval = n_eval > e->n_cus / 2 ? e->n_cus / 2 : n_eval;
+            n_eval = n_eval < 1 ? 1 : n_eval;
+            if (const char *env = getenv("AZD_POOL_EVAL_WGS")) n_eval = atoi(env) > 0 ? atoi(env) : n_eval;
+        }
+        int n_search = e->n_cus - n_eval;
+        const int want = (B + 7) / 8; // no more waves than twice the agents: a wave without an agent only polls
+        n_search = n_search > want ? want : n_search;
+        n_search = n_search < 1 ? 1 : n_search;
+        if (const char *env = getenv("AZD_POOL_SEARCH_WGS")) n_search = atoi(env) > 0 ? atoi(env) : n_search;
+        pool.n_eval = n_eval;
+        pool_blocks = n_eval + n_search;
+        e->pool_eval_wgs = n_eval;
+        e->pool_search_wgs = n_search;
+    }
+    if (use_pool || use_async || use_barrier) {
         // CU-resident forms: the whole call chain, n_calls times, in one launch per <= log_calls calls
         int left = n_calls;
         while (left > 0) {
@@ -710,13 +775,30 @@ int azd_engine_par_roll_out_episodes(azd_engine *e, const uint32_t *tol, int n_t
             e->h_pargs->a = e->a;
             e->h_pargs->tol = t;
             e->h_pargs->ev = fe;
+            e->h_pargs->pool = pool;
             AZD_HIP(hipMemcpyAsync(e->d_pargs, e->h_pargs, sizeof(azd::PersistArgs), hipMemcpyHostToDevice, e->stream));
+            if (use_pool) { // empty queues, nobody claimed, no call done
+                AZD_HIP(hipMemsetAsync(pool.ctl, 0, sizeof(azd::PoolCtl), e->stream));
+                AZD_HIP(hipMemsetAsync(pool.ready_slots, 0, e->pool_slot_words * sizeof(uint32_t), e->stream));
+                AZD_HIP(hipMemsetAsync(pool.calls_done, 0, (size_t)e->a.B * sizeof(uint32_t), e->stream));
+            }
             e->time_begin(0);
-            if (use_async) azd::launch_async(e->a, e->d_pargs, k, e->d_log_key, fe.params, fe.wpk, dyn_stride, dyn_bytes, e->stream);
+            if (use_pool) azd::launch_pool(e->a, e->d_pargs, k, e->d_log_key, fe.params, fe.wpk, pool_blocks, dyn_stride, dyn_bytes, e->stream);
+            else if (use_async) azd::launch_async(e->a, e->d_pargs, k, e->d_log_key, fe.params, fe.wpk, dyn_stride, dyn_bytes, e->stream);
             else azd::launch_persist(e->a, e->d_pargs, k, e->d_log_key, e->d_log_node, dyn_stride, dyn_bytes, e->stream);
             e->time_end();
             e->ev->calls += (uint64_t)k;
             left -= k;
+            if (use_pool) { // a wait that ran into its bound ends the launch instead of hanging it: report, do not go on
+                uint32_t ab = 0;
+                AZD_HIP(hipMemcpyAsync(&ab, &pool.ctl->abort, sizeof(ab), hipMemcpyDeviceToHost, e->stream));
+                AZD_HIP(hipStreamSynchronize(e->stream));
+                if (ab) {
+                    e->time_collect();
+                    azd::g_last_error = "pool step: a queue wait ran into its bound (no evaluator or searcher workgroup made progress)";
+                    return AZD_ERR_UNREACHABLE;
+                }
+            }
         }
         AZD_HIP(hipGetLastError());
     } else {
@@ -1116,6 +1198,26 @@ int azd_engine_timing(azd_engine *e, double *tree_ms, double *evaluator_ms, uint
     return AZD_OK;
 }
 void *azd_engine_stream(azd_engine *e) { return e ? (void *)e->stream : nullptr; }
+int azd_engine_pool_split(azd_engine *e, int *eval_wgs, int *search_wgs) {
+    if (!e) return AZD_ERR_INVALID_ARGUMENT;
+    if (eval_wgs) *eval_wgs = e->pool_eval_wgs;
+    if (search_wgs) *search_wgs = e->pool_search_wgs;
+    return AZD_OK;
+}
+int azd_debug_probe_xcc(int device, uint32_t *out, int n_blocks) {
+    if (!out || n_blocks <= 0) return AZD_ERR_INVALID_ARGUMENT;
+    int st = azd::device_ok(device);
+    if (st) return st;
+    AZD_HIP(hipSetDevice(device));
+    uint32_t *d = nullptr;
+    AZD_HIP(hipMalloc(&d, (size_t)n_blocks * 4));
+    azd::launch_probe_xcc(d, n_blocks, nullptr);
+    hipError_t he = hipDeviceSynchronize();
+    if (he == hipSuccess) he = hipMemcpy(out, d, (size_t)n_blocks * 4, hipMemcpyDeviceToHost);
+    (void)hipFree(d);
+    if (he != hipSuccess) return azd::hip_fail(he, "probe_xcc");
+    return AZD_OK;
+}
 int azd_engine_step_form(azd_engine *e, int *form, const char **reason) {
     if (!e) return AZD_ERR_INVALID_ARGUMENT;
     if (form) *form = e->step_form;

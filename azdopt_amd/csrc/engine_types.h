@@ -176,10 +176,43 @@ struct TolTable {
     uint32_t tol_default;
 };
 
+// ---- pool step (pool_step.inc): agents are not bound to waves.  Searcher workgroups pull ready agents from
+// per-XCD queues, evaluator workgroups pull batches of posted rows from per-XCD queues; all in device memory.
+constexpr int POOL_XCDS = 8;
+struct PoolQ { // head and tail on cache lines of their own
+    uint32_t head, pad0[31];
+    uint32_t tail, pad1[31];
+};
+struct PoolCtl {
+    uint32_t claim_next, pad0[31];  // next agent no searcher has taken yet in this launch
+    uint32_t done_agents, pad1[31]; // agents through all their calls
+    uint32_t abort, pad2[31];       // a wait ran into its bound: every loop leaves
+    PoolQ ready[POOL_XCDS];         // agents whose prediction row has arrived, by home XCD
+    PoolQ evalq[POOL_XCDS];         // agents waiting for a prediction row, by home XCD
+};
+struct PendRec { // what a call that ended on a new node leaves for the add_actions that follows the evaluator
+    uint32_t pos;
+    float c;
+    uint32_t n_preds;
+    uint32_t home;
+};
+struct PoolArgs {
+    PoolCtl *ctl;
+    uint32_t *ready_slots; // [POOL_XCDS][qcap]  agent + 1, 0 = empty
+    uint32_t *eval_slots;  // [POOL_XCDS][qcap]  (agent + 1) | home XCD << 24
+    uint32_t qcap;         // power of two >= 2 * B
+    uint32_t *calls_done;  // [B] calls of this launch the agent has completed
+    PendRec *pend;         // [B]
+    int n_eval;            // blocks [0, n_eval) are evaluator workgroups
+    uint32_t eval_stride;  // floats per row of an evaluator batch in LDS
+    uint32_t eval_out_off; // offset (floats) of the head's output inside a row
+};
+
 struct PersistArgs { // argument block of the persistent step, read from device memory
     Arenas a;
     TolTable tol;
     FusedEval ev;
+    PoolArgs pool;
 };
 
 // kernel launchers (tree_kernels.hip); all asynchronous on `stream`.  The *_plan functions lay out the LDS of a
@@ -193,6 +226,14 @@ bool async_plan(const Arenas &a, const FusedEval &ev, uint32_t *dyn_stride, size
 void launch_async(const Arenas &a, const PersistArgs *d_args, int n_calls, unsigned long long *log_key,
                   const float *params, const void *wpk, uint32_t dyn_stride, size_t dyn_bytes, void *stream);
 bool persist_plan(const Arenas &a, const FusedEval &ev, uint32_t *dyn_stride, size_t *dyn_bytes, const char **why = nullptr);
+// pool step (pool_kernels.hip / ramsey_pool_kernels.hip): the plan also lays out an evaluator batch (pool->eval_*)
+bool pool_plan(const Arenas &a, const FusedEval &ev, PoolArgs *pool, uint32_t *dyn_stride, size_t *dyn_bytes, const char **why = nullptr);
+void launch_pool(const Arenas &a, const PersistArgs *d_args, int n_calls, unsigned long long *log_key, const float *params,
+                 const void *wpk, int n_blocks, uint32_t dyn_stride, size_t dyn_bytes, void *stream);
+bool ramsey_pool_plan(const Arenas &a, const FusedEval &ev, PoolArgs *pool, uint32_t *dyn_stride, size_t *dyn_bytes, const char **why = nullptr);
+void ramsey_launch_pool(const Arenas &a, const PersistArgs *d_args, int n_calls, unsigned long long *log_key, const float *params,
+                        const void *wpk, int n_blocks, uint32_t dyn_stride, size_t dyn_bytes, void *stream);
+void launch_probe_xcc(uint32_t *d_out, int n_blocks, void *stream); // HW_REG_XCC_ID of every block of a launch (tests)
 void launch_persist(const Arenas &a, const PersistArgs *d_args, int n_calls, unsigned long long *log_key,
                     uint32_t *log_node, uint32_t dyn_stride, size_t dyn_bytes, void *stream);
 void launch_c21_modify_roots(const Arenas &a, uint64_t seed, uint64_t epoch, uint64_t first_agent, int kmin, int kmax,

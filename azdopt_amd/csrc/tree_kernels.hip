@@ -35,7 +35,38 @@ __global__ void k_hash_predictions(float *out, int batch, int action_dim, uint64
     }
 
 #include "persistent_step.inc"
-#ifdef AZD_TU_ASYNC
+#ifdef AZD_TU_POOL
+#include "async_step.inc"
+#include "pool_step.inc"
+template <class SP>
+static void l_pool(const Arenas &a, const PersistArgs *d_args, int n_calls, unsigned long long *log_key, const float *params,
+                   const void *wpk, int n_blocks, uint32_t dyn_stride, size_t dyn_bytes, hipStream_t st) {
+    // the dynamic-LDS attribute is per device: set on every launch (see l_async)
+    if (hipFuncSetAttribute((const void *)k_pool<SP>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn_bytes) != hipSuccess) return;
+    (void)hipMemsetAsync(log_key, 0xFF, (size_t)n_calls * sizeof(unsigned long long), st);
+    k_pool<SP><<<dim3(n_blocks), dim3(PERSIST_WAVES * 64), dyn_bytes, st>>>(d_args, n_calls, log_key, dyn_stride, params, a.state_vecs, a.h_theta, wpk);
+    k_argmin_log1<SP><<<dim3(1), dim3(64), SP::dyn_bytes(a), st>>>(a, n_calls, log_key);
+}
+void launch_pool(const Arenas &a, const PersistArgs *d_args, int n_calls, unsigned long long *log_key, const float *params,
+                 const void *wpk, int n_blocks, uint32_t dyn_stride, size_t dyn_bytes, void *stream) {
+    if (a.space == SPACE_RAMSEY) return ramsey_launch_pool(a, d_args, n_calls, log_key, params, wpk, n_blocks, dyn_stride, dyn_bytes, stream);
+    DISPATCH_KW(a, l_pool, a, d_args, n_calls, log_key, params, wpk, n_blocks, dyn_stride, dyn_bytes, (hipStream_t)stream);
+}
+__global__ void k_probe_xcc(uint32_t *out) {
+    if (threadIdx.x == 0) out[blockIdx.x] = pool_xcc_id();
+}
+void launch_probe_xcc(uint32_t *d_out, int n_blocks, void *stream) {
+    k_probe_xcc<<<dim3(n_blocks), dim3(64), 0, (hipStream_t)stream>>>(d_out);
+}
+// LDS plan of the pool step: a searcher wave's scratch (with room to build its state-vector row) or an evaluator's
+// batch of 16 rows [x][h0][h1][out], whichever is larger
+bool pool_plan(const Arenas &a, const FusedEval &ev, PoolArgs *pool, uint32_t *dyn_stride, size_t *dyn_bytes, const char **why) {
+    const char *dummy;
+    if (!why) why = &dummy;
+    if (a.space == SPACE_RAMSEY) return ramsey_pool_plan(a, ev, pool, dyn_stride, dyn_bytes, why);
+    return pool_plan_common(a, ev, pool, dyn_stride, dyn_bytes, why, C21Space<1>::pool_dyn_bytes(a), sizeof(WaveLds));
+}
+#elif defined(AZD_TU_ASYNC)
 #include "async_step.inc"
 template <class SP>
 static void l_async(const Arenas &a, const PersistArgs *d_args, int n_calls, unsigned long long *log_key,

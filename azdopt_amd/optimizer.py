@@ -46,14 +46,19 @@ class NablaOptimizer:
     `init_states` and `modify_root` closures stay on the host and hand over packed roots."""
 
     def __init__(self, space, model, batch, device=0, first_agent=0, node_capacity=0, arc_capacity=0,
-                 prediction_capacity=0, path=ActionSet, persistent=True, async_step=True):
+                 prediction_capacity=0, path=ActionSet, persistent=True, async_step=True, pool_step=None):
+        """step form: pool_step=None lets the engine choose (pool step from 256 agents, else the asynchronous one),
+        True / False force the pool / asynchronous step, async_step=False the lock-step one, persistent=False one
+        launch per phase"""
         if not hasattr(path, "PATH_KIND") or not path.licensed_for(space):
             raise TypeError("path encoding %r is not licensed for this space (space/axioms.rs:12-19)" % (path,))
         self.space, self.model, self.batch, self.first_agent = space, model, batch, first_agent
         self._L = _lib.lib()
         cfg = _lib.EngineConfig(space.SPACE_ID, space.n, batch, device, node_capacity, arc_capacity,
                                 prediction_capacity, first_agent,
-                                (0 if persistent else _lib.ENGINE_NO_PERSISTENT_STEP) | (0 if async_step else _lib.ENGINE_BARRIER_STEP))
+                                (0 if persistent else _lib.ENGINE_NO_PERSISTENT_STEP) | (0 if async_step else _lib.ENGINE_BARRIER_STEP)
+                                | (_lib.ENGINE_POOL_STEP if pool_step else 0)
+                                | (_lib.ENGINE_ASYNC_STEP if (pool_step is False and async_step) else 0))
         cfg.path_kind = path.PATH_KIND
         cfg.layers = getattr(space, "layers", 1)
         if space.SPACE_ID == _lib.SPACE_RAMSEY:
@@ -267,7 +272,13 @@ class NablaOptimizer:
     def stream(self):
         return self._L.azd_engine_stream(self._h)
 
-    STEP_FORMS = {0: "none", 1: "async", 2: "barrier", 3: "per_call"}
+    STEP_FORMS = {0: "none", 1: "async", 2: "barrier", 3: "per_call", 4: "pool"}
+
+    def pool_split(self):
+        """(evaluator, searcher) workgroups of the last pool-step launch"""
+        a, b = C.c_int32(), C.c_int32()
+        _lib.check(self._L.azd_engine_pool_split(self._h, C.byref(a), C.byref(b)), "pool_split")
+        return a.value, b.value
 
     def step_form(self):
         """(form, reason) of the last par_roll_out_episodes: "async" / "barrier" (CU-resident) or "per_call"

@@ -147,6 +147,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--chunk", type=int, default=800, help="calls per host round trip (<= one epoch)")
     ap.add_argument("--barrier-step", action="store_true", help="lock-step form (k_persist) instead of the default asynchronous step (k_async)")
+    ap.add_argument("--step", choices=["async", "barrier", "pool"], default=None,
+                    help="force a step form (default: the engine's choice -- the pool step k_pool from 256 agents, else k_async)")
     ap.add_argument("--config", choices=sorted(CONFIGS), default=None,
                     help="BASELINE.json preset: A reference shape (512 agents, 512-1024-512 MLP), B 4096 agents fp32 (default), "
                          "C 8192 agents/GPU bf16 (65536 at --gpus 8), D Ramsey r44 8192 agents/GPU")
@@ -193,7 +195,8 @@ def main():
         space, lambda total: az.ActionModel(total, space.STATE_DIM, space.ACTION_DIM, hidden=HIDDEN, seed=SEED,
                                             device=local_rank, dtype=mlp_dtype),
         AGENTS_PER_GPU, dist=dist if world > 1 else None, torch=torch, seed=SEED, device_index=local_rank, rank=rank,
-        world_size=world, stage_on_cpu=rehearse, async_step=not args.barrier_step, **wl["caps"])
+        world_size=world, stage_on_cpu=rehearse, async_step=not (args.barrier_step or args.step == "barrier"),
+        pool_step={"pool": True, "async": False, "barrier": False}.get(args.step), **wl["caps"])
     opt = sopt.shard.opt  # this rank's NablaOptimizer (counters, timing)
     B, B_total = sopt.plan.local_agents, sopt.plan.total_agents
     coll_dev = sopt.coll_device
@@ -270,7 +273,7 @@ def main():
         avg_ms = timing["rollout_ms"] / launches
         bytes_per_launch = bytes_per_exp * exp_local / launches
         achieved = bytes_per_launch / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
-        kernel = {"async": "k_async<%d>", "barrier": "k_persist<%d>", "per_call": "k_rollout<%d>"}.get(form, "?<%d>") % kw
+        kernel = {"async": "k_async<%d>", "barrier": "k_persist<%d>", "per_call": "k_rollout<%d>", "pool": "k_pool<%d>"}.get(form, "?<%d>") % kw
         # HBM traffic is not measured by this process (PMC counters need rocprofv3): it is the per-call figure of the
         # committed profile of the same kernel and workload, scaled to this run's calls per launch, or null
         traffic, traffic_src = None, None
@@ -302,7 +305,7 @@ def main():
                                       str(TOL[0]).replace(" ", ""), TOL[1], window),
                        "baseline_config": args.config or ("B" if (wl_name, AGENTS_PER_GPU, mlp_dtype) == CONFIGS["B"] else None),
                        "agents_total": B_total, "parallelism": f"agents sharded x{world}"},
-            "step_form": form, "step_form_reason": form_why,
+            "step_form": form, "step_form_reason": form_why, "pool_split": list(opt.pool_split()) if form == "pool" else None,
             "epoch_boundary_in_timed_region": n_bound > 0, "epoch_boundaries_in_timed_region": n_bound,
             "best_cost_found": best_cost, "best_eval": best_eval,
             "expansions": exp_total, "terminals": d["TERMINALS"], "transpositions": d["TRANSPOSITIONS"],

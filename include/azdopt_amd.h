@@ -188,14 +188,22 @@ typedef struct azd_engine_config {
 /* run every phase of a call as its own kernel launch instead of the CU-resident persistent step
  * (the two forms produce identical trees; the persistent step is the fast one) */
 #define AZD_ENGINE_NO_PERSISTENT_STEP 1u
-/* The CU-resident step comes in two forms with identical results.  Default: the asynchronous one
- * (k_async: the agents of a workgroup drift apart, an agent waiting for its prediction row serves
- * MFMA tile tasks of the workgroup's evaluator; hidden layer widths in multiples of 16 and an input
- * width in multiples of 4, else the engine falls back by itself).  AZD_ENGINE_BARRIER_STEP selects the lock-step form (k_persist: a
- * workgroup barrier around the evaluator on every call), 12 % slower at 4096 agents
- * (profiles/README.md).  AZD_ENGINE_ASYNC_STEP is accepted for compatibility and changes nothing. */
+/* The CU-resident step comes in three forms with identical results.  With none of the three flags below the
+ * engine takes the pool step for populations of 256 agents and more and the asynchronous step below that, and
+ * falls back by itself (pool -> asynchronous -> lock-step -> one launch per phase) when a form cannot take the
+ * model; azd_engine_step_form says which form ran and why.
+ * AZD_ENGINE_ASYNC_STEP: k_async -- one workgroup = 16 agents on 16 wavefronts, the agents of a workgroup drift
+ * apart, an agent waiting for its prediction row serves MFMA tile tasks of the workgroup's evaluator (hidden layer
+ * widths in multiples of 16, input width in multiples of 4).
+ * AZD_ENGINE_BARRIER_STEP: k_persist -- the same residency in lock-step (a workgroup barrier around the evaluator
+ * on every call), 12 % slower at 4096 agents (profiles/README.md). */
 #define AZD_ENGINE_ASYNC_STEP 2u
 #define AZD_ENGINE_BARRIER_STEP 4u
+/* Third CU-resident form, identical results again (k_pool): agents are not bound to wavefronts -- searcher
+ * workgroups pull ready agents from per-XCD queues and never wait for a prediction row, evaluator workgroups on
+ * CUs of their own pull batches of up to 16 posted rows (full MFMA row tiles, an undisturbed weight stream).
+ * Populations larger than the resident waves share them instead of running as serial rounds of workgroups. */
+#define AZD_ENGINE_POOL_STEP 8u
 
 /* ArgminData<State, Cost> (az-discrete-opt/src/log.rs:1-11) for the c21 space */
 typedef struct azd_argmin {
@@ -351,7 +359,12 @@ void *azd_engine_stream(azd_engine *e); /* hipStream_t the engine launches on */
 #define AZD_STEP_ASYNC 1
 #define AZD_STEP_BARRIER 2
 #define AZD_STEP_PER_CALL 3
+#define AZD_STEP_POOL 4
 int azd_engine_step_form(azd_engine *e, int *form, const char **reason);
+/* how the last pool-step launch split the CUs: evaluator / searcher workgroups */
+int azd_engine_pool_split(azd_engine *e, int *eval_wgs, int *search_wgs);
+/* HW_REG_XCC_ID read by every block of an n_blocks launch (the pool step keeps a tree on the XCD that first took it) */
+int azd_debug_probe_xcc(int device, uint32_t *out, int n_blocks);
 
 /* Parity probe for the two f32 primitives the selection rule (tree/next_action.rs:70,81) depends
  * on bit-for-bit.  in: 2*n floats (pairs x, y); out: 4*n floats per pair:

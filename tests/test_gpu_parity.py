@@ -383,12 +383,13 @@ def test_async_epoch_is_reproducible_at_full_size(az):
     space = az.ROTModifyParentsOnce(n)
     roots = space.generate_roots(0, B)
     runs = []
-    for async_step in (True, True, False):
+    for kw in (dict(pool_step=False), dict(pool_step=False), dict(async_step=False), dict()):  # async twice, barrier, the engine's default (pool)
         model = az.ActionModel(B, space.STATE_DIM, space.ACTION_DIM, hidden=(256, 256, 256), seed=0)
-        o = az.NablaOptimizer.par_new(space, roots, model, B, async_step=async_step)
+        o = az.NablaOptimizer.par_new(space, roots, model, B, **kw)
         imp = o.par_roll_out_episodes(TOL_REF, n_calls=calls)
         runs.append((o, imp))
     o0, i0 = runs[0]
+    assert [o.step_form()[0] for o, _ in runs] == ["async", "async", "barrier", "pool"]
     c0, a0 = o0.counters(), o0.argmin_data()
     assert c0["EXPANSIONS"] > 0.8 * B * calls and c0["EVAL_ROWS"] == c0["EXPANSIONS"]
     for o, imp in runs[1:]:

@@ -1,0 +1,167 @@
+"""GPU tests of the pool step (k_pool: agents multiplexed over searcher waves through per-XCD queues, evaluator
+workgroups on CUs of their own): same trees, counters, argmin and prediction rows as the other step forms and as
+the oracle, whatever wave ran which call and whichever batch carried which row."""
+import numpy as np
+import pytest
+
+from test_gpu_parity import MAIN_CTRS, TOL_REF, assert_tree_equal
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def az():
+    import azdopt_amd
+    assert azdopt_amd.device_count() > 0, "no MI355X visible"
+    return azdopt_amd
+
+
+def same_engines(o1, i1, o2, i2, agents):
+    assert i1 == i2
+    c1, c2 = o1.counters(), o2.counters()
+    for k in MAIN_CTRS:
+        assert c1[k] == c2[k], k
+    for i in agents:
+        assert_tree_equal(o1.get_tree(i), o2.get_tree(i), f"agent {i}")
+    a1, a2 = o1.argmin_data(), o2.argmin_data()
+    assert a1.eval == a2.eval and a1.agent == a2.agent and a1.node == a2.node
+    assert np.array_equal(o1.state_vecs(), o2.state_vecs())
+
+
+def test_xcc_ids_cover_the_chip(az):
+    """the pool step keeps a tree on the XCD whose searcher first took it: HW_REG_XCC_ID must tell XCDs apart"""
+    from azdopt_amd import _lib
+    out = np.full(256, 99, np.uint32)
+    _lib.check(az.lib().azd_debug_probe_xcc(0, _lib.ptr(out), 256), "probe_xcc")
+    assert out.max() <= 7
+    counts = np.bincount(out, minlength=8)
+    assert (counts > 0).sum() >= 1 and counts.sum() == 256
+    print("blocks per XCC id:", counts.tolist())
+
+
+def test_pool_step_hash_stream_equals_oracle_and_async(az, orc):
+    n, B, seed, calls = 19, 200, 6, 150
+    space = az.ROTModifyParentsOnce(n)
+    roots = space.generate_roots(seed, B)
+    opts = []
+    for kw in (dict(pool_step=True), dict(pool_step=False)):
+        model = az.HashStreamModel(space.STATE_DIM, space.ACTION_DIM, seed)
+        o = az.NablaOptimizer.par_new(space, roots, model, B, **kw)
+        imp = o.par_roll_out_episodes(TOL_REF, n_calls=calls)
+        opts.append((o, imp))
+    assert opts[0][0].step_form()[0] == "pool" and opts[1][0].step_form()[0] == "async"
+    same_engines(opts[0][0], opts[0][1], opts[1][0], opts[1][1], range(B))
+    oe = orc.Engine(n, B, threads=8)
+    oe.new_begin(*roots)
+    oe.new_end(orc.hash_predictions(seed, 0, B, space.ACTION_DIM, 0))
+    for call in range(1, calls + 1):
+        oe.rollout_begin(*TOL_REF)
+        oe.rollout_end(orc.hash_predictions(seed, 0, B, space.ACTION_DIM, call))
+    for i in range(0, B, 9):
+        assert_tree_equal(opts[0][0].get_tree(i), oe.export_tree(i), f"agent {i}")
+
+
+@pytest.mark.parametrize("dtype", ["f32", "bf16"])
+def test_pool_step_with_mlp_equals_async_and_barrier(az, dtype):
+    """the evaluator workgroups run the same MFMA sequence per output element as the other forms' in-kernel
+    evaluators: identical prediction rows, hence identical trees after many calls in one launch"""
+    n, B, seed, calls = 19, 200, 9, 120
+    space = az.ROTModifyParentsOnce(n)
+    roots = space.generate_roots(seed, B)
+    runs = []
+    forms = (dict(pool_step=True), dict(pool_step=False)) + ((dict(async_step=False),) if dtype == "f32" else ())
+    for kw in forms:
+        model = az.ActionModel(B, space.STATE_DIM, space.ACTION_DIM, hidden=(256, 256, 256), seed=seed, dtype=dtype)
+        o = az.NablaOptimizer.par_new(space, roots, model, B, **kw)
+        imp = o.par_roll_out_episodes(TOL_REF, n_calls=calls)
+        runs.append((o, imp))
+    assert runs[0][0].step_form() == ("pool", "")
+    ev, se = runs[0][0].pool_split()
+    assert ev >= 1 and se >= 1
+    c = runs[0][0].counters()
+    assert c["EVAL_ROWS"] == c["EXPANSIONS"] and c["FAILED"] == 0
+    for o, imp in runs[1:]:
+        same_engines(runs[0][0], runs[0][1], o, imp, range(0, B, 3))
+        assert np.array_equal(runs[0][0].predictions().view(np.uint32), o.predictions().view(np.uint32))
+
+
+def test_pool_step_call_by_call_against_the_oracle(az, orc):
+    n, B, seed = 19, 72, 4
+    space = az.ROTModifyParentsOnce(n)
+    model = az.ActionModel(B, space.STATE_DIM, space.ACTION_DIM, hidden=(256, 256, 256), seed=seed)
+    parents, permitted = space.generate_roots(seed, B)
+    opt = az.NablaOptimizer.par_new(space, (parents, permitted), model, B, pool_step=True)
+    oe = orc.Engine(n, B, threads=8)
+    oe.new_begin(parents, permitted)
+    oe.new_end(opt.predictions())
+    for s in range(60):
+        opt.par_roll_out_episodes(TOL_REF)
+        oe.rollout_begin(*TOL_REF)
+        assert np.array_equal(opt.state_vecs(), oe.state_vecs())
+        oe.rollout_end(opt.predictions())
+    assert opt.step_form()[0] == "pool"
+    for i in range(B):
+        assert_tree_equal(opt.get_tree(i), oe.export_tree(i), f"agent {i}")
+    assert np.isfinite(opt.par_update_model(5))
+
+
+@pytest.mark.parametrize("B", [4096, 8192])
+def test_pool_step_full_epoch_equals_async(az, B):
+    """a whole epoch in one launch: 4096 agents (BASELINE config B) and 8192 (more agents than resident searcher waves:
+    every agent migrates between waves and CUs of its XCD many times)"""
+    n, calls = 19, 800
+    space = az.ROTModifyParentsOnce(n)
+    roots = space.generate_roots(0, B)
+    runs = []
+    for kw in (dict(pool_step=True), dict(pool_step=False)):
+        model = az.ActionModel(B, space.STATE_DIM, space.ACTION_DIM, hidden=(256, 256, 256), seed=0)
+        o = az.NablaOptimizer.par_new(space, roots, model, B, **kw)
+        imp = o.par_roll_out_episodes(TOL_REF, n_calls=calls)
+        runs.append((o, imp))
+    assert runs[0][0].step_form()[0] == "pool"
+    same_engines(runs[0][0], runs[0][1], runs[1][0], runs[1][1], range(0, B, 257))
+    assert np.array_equal(runs[0][0].predictions().view(np.uint32), runs[1][0].predictions().view(np.uint32))
+    # the epoch boundary after a pool launch, and a second epoch on top of it
+    for o, _ in runs:
+        o.par_update_model(200)
+        o.par_reset_trees_policy(0, 0)
+    imps = [o.par_roll_out_episodes(TOL_REF, n_calls=100) for o, _ in runs]
+    same_engines(runs[0][0], imps[0], runs[1][0], imps[1], range(0, B, 511))
+
+
+def test_pool_step_reference_shape_and_ramsey(az):
+    space = az.ROTModifyParentsOnce(19)
+    B = 512
+    roots = space.generate_roots(5, B)
+    runs = []
+    for kw in (dict(pool_step=True), dict(pool_step=False)):
+        model = az.ActionModel(B, space.STATE_DIM, space.ACTION_DIM, hidden=(512, 1024, 512), seed=5)
+        o = az.NablaOptimizer.par_new(space, roots, model, B, **kw)
+        runs.append((o, o.par_roll_out_episodes(TOL_REF, n_calls=100)))
+    assert runs[0][0].step_form() == ("pool", "")
+    same_engines(runs[0][0], runs[0][1], runs[1][0], runs[1][1], range(0, B, 31))
+    rs = az.RamseySpaceNoEdgeRecolor(16, [3, 3, 3])
+    tol = ([200, 200, 200, 100, 100, 100, 50, 50, 50, 25, 25, 25], 10)
+    B = 300
+    roots = rs.generate_roots(2, B)
+    runs = []
+    for kw in (dict(pool_step=True), dict(pool_step=False)):
+        model = az.ActionModel(B, rs.STATE_DIM, rs.ACTION_DIM, hidden=(256, 256, 256), seed=2)
+        o = az.NablaOptimizer.par_new(rs, roots, model, B, prediction_capacity=98304, **kw)
+        runs.append((o, o.par_roll_out_episodes(tol, n_calls=150)))
+    assert runs[0][0].step_form() == ("pool", "")
+    assert runs[0][1] == runs[1][1]
+    c1, c2 = runs[0][0].counters(), runs[1][0].counters()
+    for k in MAIN_CTRS:
+        assert c1[k] == c2[k], k
+    for i in range(0, B, 17):
+        assert_tree_equal(runs[0][0].get_tree(i), runs[1][0].get_tree(i), f"ramsey agent {i}")
+
+
+def test_pool_step_reports_capacity_overflow(az):
+    space = az.ROTModifyParentsOnce(19)
+    model = az.ActionModel(32, space.STATE_DIM, space.ACTION_DIM, hidden=(64, 64), seed=0)
+    opt = az.NablaOptimizer.par_new(space, space.generate_roots(0, 32), model, 32, prediction_capacity=600, pool_step=True)
+    with pytest.raises(az.AzdError) as ei:
+        opt.par_roll_out_episodes(TOL_REF, n_calls=200)
+    assert ei.value.status == 4 and opt.counters()["FAILED"] > 0

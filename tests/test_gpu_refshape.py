@@ -27,7 +27,7 @@ def test_reference_shape_runs_on_the_async_step_with_oracle_parity(az, orc):
     space = az.ROTModifyParentsOnce(n)
     model = az.ActionModel(B, space.STATE_DIM, space.ACTION_DIM, hidden=REF_HIDDEN, seed=seed)
     parents, permitted = space.generate_roots(seed, B)
-    opt = az.NablaOptimizer.par_new(space, (parents, permitted), model, B)
+    opt = az.NablaOptimizer.par_new(space, (parents, permitted), model, B, pool_step=False)
     oe = orc.Engine(n, B, threads=8)
     oe.new_begin(parents, permitted)
     oe.new_end(opt.predictions())
@@ -65,7 +65,7 @@ def test_reference_shape_many_calls_per_launch_all_forms_agree(az):
     runs = []
     for async_step in (True, False):
         model = az.ActionModel(B, space.STATE_DIM, space.ACTION_DIM, hidden=REF_HIDDEN, seed=seed)
-        o = az.NablaOptimizer.par_new(space, roots, model, B, async_step=async_step)
+        o = az.NablaOptimizer.par_new(space, roots, model, B, async_step=async_step, pool_step=False)
         imp = o.par_roll_out_episodes(TOL_REF, n_calls=200)
         runs.append((o, imp))
     assert runs[0][0].step_form()[0] == "async"
@@ -107,7 +107,7 @@ def test_prediction_capacity_overflow_is_reported(az, persistent, async_step):
     space = az.ROTModifyParentsOnce(19)
     model = az.HashStreamModel(space.STATE_DIM, space.ACTION_DIM, 0)
     opt = az.NablaOptimizer.par_new(space, space.generate_roots(0, 32), model, 32, prediction_capacity=600,
-                                    persistent=persistent, async_step=async_step)
+                                    persistent=persistent, async_step=async_step, pool_step=False)
     with pytest.raises(az.AzdError) as ei:
         opt.par_roll_out_episodes(TOL_REF, n_calls=200)
     assert ei.value.status == 4  # AZD_ERR_CAPACITY

@@ -101,7 +101,7 @@ def test_engines_on_two_devices_in_one_process(az):
         model = az.ActionModel(B, space.STATE_DIM, space.ACTION_DIM, hidden=(512, 1024, 512), seed=1, device=dev)
         o = az.NablaOptimizer.par_new(space, roots, model, B, device=dev)
         o.par_roll_out_episodes(TOL_REF, n_calls=30)
-        assert o.step_form()[0] == "async"
+        assert o.step_form()[0] == "async"  # 64 agents: below the pool step's threshold
         res.append(o.counters())
     for k in MAIN_CTRS:
         assert res[0][k] == res[1][k], k
