@@ -160,6 +160,106 @@ __global__ __launch_bounds__(256) void k_gemm(const float *__restrict__ A, int l
     }
 }
 
+// ---- batched bf16 GEMM for inference under AZD_STORAGE_BF16 (write_predictions_dev, par_new / par_reset_trees rows,
+// the launch-per-phase step): Y[M,N] = act(bf16(X)[M,K] . W16[N,K]^T + b), products exact, f32 accumulation on
+// v_mfma_f32_32x32x16_bf16 (the dfdx forward of model/dfdx.rs:82,116 with bf16 storage).
+//   block = 256 threads = 4 waves (2 x 2), tile 128 x 128 x 32; a wave owns 64 x 64 = 2 x 2 MFMA tiles (64 accumulator
+//   VGPRs); X rows are read as f32 and rounded to bf16 (RNE, bf16.h) on their way into LDS, W16 rows are bf16 already;
+//   both tiles sit in LDS k-contiguous with an 80-byte row pitch, so that an operand fragment (8 consecutive k of one
+//   row: lane l holds A[l & 31][8 (l >> 5) + j], B[8 (l >> 5) + j][l & 31]) is one 16-byte ds_read; the next k tile's
+//   global loads are in flight while the current one is multiplied.
+// K and the row pitches must be multiples of 4 (16-byte f32 / 8-byte bf16 vector loads); other shapes take k_gemm.
+typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
+constexpr int GB_M = 128, GB_N = 128, GB_K = 32, GB_LD = 40; // LDS row pitch in bf16 elements (80 B)
+__global__ __launch_bounds__(256, 2) void k_gemm_bf16(const float *__restrict__ X, int ldx, const uint16_t *__restrict__ W, int ldw,
+                                                      float *__restrict__ Y, int ldy, int M, int N, int K, int act, int round_out,
+                                                      const float *__restrict__ bias) {
+    __shared__ __attribute__((aligned(16))) uint16_t sA[GB_M * GB_LD];
+    __shared__ __attribute__((aligned(16))) uint16_t sB[GB_N * GB_LD];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int m0 = blockIdx.y * GB_M, n0 = blockIdx.x * GB_N;
+    // staging: thread t moves 16 consecutive k of row t >> 1 (A: four float4, B: four 8-byte groups)
+    const int srow = tid >> 1, skof = (tid & 1) * 16;
+    const float *xa = X + (size_t)(m0 + srow) * ldx + skof;
+    const uint16_t *wb = W + (size_t)(n0 + srow) * ldw + skof;
+    const bool a_ok = m0 + srow < M, b_ok = n0 + srow < N;
+    float4 ra[4];
+    uint2 rb[4];
+    auto fetch = [&](int k0) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int k = k0 + skof + 4 * q;
+            ra[q] = (a_ok && k < K) ? *reinterpret_cast<const float4 *>(xa + k0 + 4 * q) : make_float4(0.f, 0.f, 0.f, 0.f);
+            rb[q] = (b_ok && k < K) ? *reinterpret_cast<const uint2 *>(wb + k0 + 4 * q) : make_uint2(0u, 0u);
+        }
+    };
+    auto stash = [&]() {
+        uint32_t pa[8];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            pa[2 * q] = bf16_bits(ra[q].x) | (bf16_bits(ra[q].y) << 16);
+            pa[2 * q + 1] = bf16_bits(ra[q].z) | (bf16_bits(ra[q].w) << 16);
+        }
+        uint4 *da = reinterpret_cast<uint4 *>(sA + srow * GB_LD + skof);
+        da[0] = make_uint4(pa[0], pa[1], pa[2], pa[3]);
+        da[1] = make_uint4(pa[4], pa[5], pa[6], pa[7]);
+        uint4 *db = reinterpret_cast<uint4 *>(sB + srow * GB_LD + skof);
+        db[0] = make_uint4(rb[0].x, rb[0].y, rb[1].x, rb[1].y);
+        db[1] = make_uint4(rb[2].x, rb[2].y, rb[3].x, rb[3].y);
+    };
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    fetch(0);
+    for (int k0 = 0; k0 < K; k0 += GB_K) {
+        stash();
+        __syncthreads();
+        if (k0 + GB_K < K) fetch(k0 + GB_K);
+        const int fr = lane & 31, fh = (lane >> 5) * 8;
+#pragma unroll
+        for (int ks = 0; ks < GB_K; ks += 16) {
+            bf16x8_t fa[2], fb[2];
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const uint4 va = *reinterpret_cast<const uint4 *>(sA + (wm * 64 + i * 32 + fr) * GB_LD + ks + fh);
+                const uint4 vb = *reinterpret_cast<const uint4 *>(sB + (wn * 64 + i * 32 + fr) * GB_LD + ks + fh);
+                __builtin_memcpy(&fa[i], &va, 16);
+                __builtin_memcpy(&fb[i], &vb, 16);
+            }
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i], fb[j], acc[i][j], 0, 0, 0);
+        }
+        __syncthreads();
+    }
+    // epilogue: C/D layout col = lane & 31, row = (r & 3) + 8 (r >> 2) + 4 (lane >> 5)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int col = n0 + wn * 64 + j * 32 + (lane & 31);
+        if (col >= N) continue;
+        const float bj = bias ? bias[col] : 0.f;
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = m0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                if (row < M) {
+                    float v = acc[i][j][r] + bj;
+                    if (act == AZD_ACT_RELU) v = v > 0.f ? v : 0.f;
+                    else if (act == AZD_ACT_SIGMOID) v = 1.0f / (1.0f + expf(-v));
+                    if (round_out) v = bf16_round(v); // a hidden activation is the next layer's bf16 input
+                    Y[(size_t)row * ldy + col] = v;
+                }
+            }
+    }
+}
+
 // ---- bf16 weight storage: w16 = RNE(params) in 16-bit words, params_q = the same values widened back
 // to f32 (what the f32 GEMM path multiplies with, so that it computes what the bf16 MFMA path computes)
 __global__ void k_quantize_bf16(const float *__restrict__ p, size_t n, uint16_t *__restrict__ w16, float *__restrict__ q) {
@@ -376,6 +476,21 @@ struct MlpEvaluator : azd_evaluator {
     int forward(int batch, const float *d_s, float *d_p, hipStream_t st, bool quant = false) {
         const float *x = d_s;
         const float *P = quant ? d_params_q : d_params;
+        bool mfma16 = quant; // the bf16 MFMA GEMM takes row pitches in multiples of 4
+        for (int l = 0; l < L && mfma16; ++l) mfma16 = dims[(size_t)l] % 4 == 0 && w_off[(size_t)l] % 4 == 0;
+        if (mfma16) {
+            for (int l = 0; l < L; ++l) {
+                float *y = (l == L - 1) ? d_p : d_act[(size_t)l + 1];
+                const int K = dims[(size_t)l], N = dims[(size_t)l + 1];
+                dim3 grid((N + GB_N - 1) / GB_N, (batch + GB_M - 1) / GB_M);
+                k_gemm_bf16<<<grid, dim3(256), 0, st>>>(x, K, d_w16 + w_off[(size_t)l], K, y, N, batch, N, K,
+                                                        (l == L - 1) ? final_act : AZD_ACT_RELU, l < L - 1 ? 1 : 0,
+                                                        d_params + b_off[(size_t)l]);
+                x = y;
+            }
+            AZD_HIP(hipGetLastError());
+            return AZD_OK;
+        }
         if (quant) {
             const size_t n = (size_t)batch * dims[0];
             k_round_bf16<<<(unsigned)((n + 255) / 256), 256, 0, st>>>(d_s, n, d_xq);

@@ -15,8 +15,8 @@ class NablaModel:
         self.state_dim = self.action_dim = 0
 
     def __del__(self):
-        if getattr(self, "_h", None) and self._h.value:
-            _lib.lib().azd_evaluator_destroy(self._h)
+        if getattr(self, "_h", None) and self._h.value and _lib is not None and getattr(_lib, "lib", None):
+            _lib.lib().azd_evaluator_destroy(self._h)  # (module globals may already be gone at interpreter exit)
             self._h = C.c_void_p()
 
     def write_predictions(self, states, predictions):

@@ -34,7 +34,10 @@ def reference_forward(params, dims, x):
     return t
 
 
-@pytest.mark.parametrize("dims,B", [((304, 256, 256, 256, 152), 512), ((304, 512, 1024, 512, 152), 96), ((840, 256, 128, 360), 64)])
+# the last two: BASELINE config E's model (K = 3676 = 114.9 k tiles of 32, N = 2450 = 19.1 column tiles of 128: ragged
+# on every side of the bf16 MFMA GEMM's 128 x 128 x 32 tile) and a batch that is not a multiple of the row tile
+@pytest.mark.parametrize("dims,B", [((304, 256, 256, 256, 152), 512), ((304, 512, 1024, 512, 152), 96), ((840, 256, 128, 360), 64),
+                                    ((3676, 512, 512, 512, 2450), 200), ((304, 256, 256, 256, 152), 1300)])
 def test_bf16_gemm_path_matches_rounded_reference(az, dims, B):
     m = az.ActionModel(B, dims[0], dims[-1], hidden=dims[1:-1], seed=5, dtype="bf16")
     rng = np.random.default_rng(1)
