@@ -23,6 +23,7 @@ ENGINE_BARRIER_STEP = 4
 ENGINE_POOL_STEP = 8
 SPACE_C21 = 1
 SPACE_RAMSEY = 2
+SPACE_DENSE = 3
 PATH_SET, PATH_SEQUENCE = 0, 1
 
 
@@ -50,6 +51,11 @@ class EngineConfig(C.Structure):
 class RamseyArgmin(C.Structure):  # ArgminData<RamseyCountsNoRecolor, TotalCounts<C>>
     _fields_ = [("colors", C.c_uint8 * 256), ("permitted", C.c_uint64 * 4), ("totals", C.c_int32 * 4),
                 ("eval", C.c_float), ("agent", C.c_int32), ("node", C.c_uint32)]
+
+
+class DenseArgmin(C.Structure):  # ArgminData of the dense-graph space
+    _fields_ = [("adj", C.c_uint64 * 64), ("permitted", C.c_uint64 * 40), ("lambda_1", C.c_double),
+                ("matching_size", C.c_int32), ("eval", C.c_float), ("agent", C.c_int32), ("node", C.c_uint32)]
 
 
 class Argmin(C.Structure):  # ArgminData<State, Cost>, az-discrete-opt/src/log.rs:1-11
@@ -120,6 +126,11 @@ def lib():
     sig("azd_ramsey_key_words", C.c_int, C.c_int, C.c_int)
     sig("azd_ramsey_generate_roots", C.c_int, C.c_uint64, C.c_uint64, C.c_uint64, C.c_int, C.c_int, C.c_int, C.c_int,
         C.c_int, vp, vp)
+    sig("azd_dense_state_dim", C.c_int, C.c_int)
+    sig("azd_dense_action_dim", C.c_int, C.c_int)
+    sig("azd_dense_key_words", C.c_int, C.c_int)
+    sig("azd_dense_generate_roots", C.c_int, C.c_uint64, C.c_uint64, C.c_uint64, C.c_int, C.c_int, C.c_int, C.c_int, C.c_double, vp, vp)
+    sig("azd_engine_dense_argmin_data", C.c_int, vp, C.POINTER(DenseArgmin))
     sig("azd_c21_modify_roots", C.c_int, vp, C.c_uint64, C.c_uint64, C.c_int, C.c_int, vp, vp)
     sig("azd_c21_modify_roots_dev", C.c_int, vp, C.c_uint64, C.c_uint64, C.c_int, C.c_int, vp, vp)
     sig("azd_engine_par_reset_trees_c21", C.c_int, vp, C.c_uint64, C.c_uint64, C.c_int, C.c_int)

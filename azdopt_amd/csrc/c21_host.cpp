@@ -102,4 +102,52 @@ void ramsey_generate_roots(uint64_t seed, uint64_t epoch, uint64_t first_agent, 
     }
 }
 
+// ---- dense-graph space: seeded stand-in for ConnectedBitsetGraph::generate(p) (connected_bitset_graph/mod.rs:84-97:
+// redraw G(n, p) until it is connected) + a modifiable-slot set in the image of modify_parent_once.rs:14-25.
+//   attempt t = 0, 1, ...: the edge at slot e is present iff (draw(4096 + t E + e) >> 40) < p24 (p24 = p 2^24);
+//   modifiable slots = first k of the Fisher-Yates shuffle of 0..E-1 (draws 64 + j)
+int dense_edges(int n) { return n * (n - 1) / 2; }
+int dense_state_dim(int n) { return 3 * dense_edges(n) + 1; }
+int dense_action_dim(int n) { return 2 * dense_edges(n); }
+int dense_key_words(int n) { return (dense_action_dim(n) + 63) / 64; }
+bool dense_connected(const uint64_t *adj, int n) {
+    uint64_t seen = 1ull, frontier = 1ull;
+    const uint64_t all = n >= 64 ? ~0ull : ((1ull << n) - 1ull);
+    while (frontier) {
+        uint64_t next = 0;
+        while (frontier) {
+            const int w = __builtin_ctzll(frontier);
+            frontier &= frontier - 1;
+            next |= adj[w];
+        }
+        frontier = next & ~seen;
+        seen |= next;
+    }
+    return (seen & all) == all;
+}
+void dense_generate_roots(uint64_t seed, uint64_t epoch, uint64_t first_agent, int count, int n, int kmin, int kmax,
+                          uint32_t p24, uint64_t *adj_out, uint64_t *slots) {
+    const int E = dense_edges(n), KW = dense_key_words(n);
+    const uint64_t domain = DOMAIN_ROOT ^ (epoch << 32);
+    for (int i = 0; i < count; ++i) {
+        const uint64_t agent = first_agent + (uint64_t)i;
+        const int k = kmin + (int)draw_below(stream_key(seed, domain, agent, 0), (uint32_t)(kmax - kmin + 1));
+        uint64_t *adj = adj_out + (size_t)i * n;
+        for (uint64_t t = 0;; ++t) {
+            for (int v = 0; v < n; ++v) adj[v] = 0;
+            int e = 0;
+            for (int v = 1; v < n; ++v)
+                for (int u = 0; u < v; ++u, ++e)
+                    if ((uint32_t)(stream_key(seed, domain, agent, 4096ull + t * (uint64_t)E + (uint64_t)e) >> 40) < p24) {
+                        adj[v] |= 1ull << u;
+                        adj[u] |= 1ull << v;
+                    }
+            if (dense_connected(adj, n)) break;
+        }
+        uint64_t *so = slots + (size_t)i * KW;
+        for (int w = 0; w < KW; ++w) so[w] = 0;
+        shuffle_mask(seed, domain, agent, E, (E + 63) / 64, k, so);
+    }
+}
+
 } // namespace azd

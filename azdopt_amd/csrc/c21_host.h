@@ -34,4 +34,14 @@ void ramsey_fresh_root(uint64_t seed, uint64_t domain, uint64_t agent, int n, in
 void ramsey_generate_roots(uint64_t seed, uint64_t epoch, uint64_t first_agent, int count, int n, int c, int kmin,
                            int kmax, uint8_t *colors, uint64_t *permitted);
 
+// dense-graph space (space_dense.inc; oracle/dense_graph.inc): E = N(N-1)/2 slots, ACTION = 2E (AddOrDeleteEdge,
+// bitset_graph/space/action.rs:10-27), STATE = 3E + 1 (= E + ACTION + 1, 05-ah.rs:39-40)
+int dense_edges(int n);
+int dense_state_dim(int n);
+int dense_action_dim(int n);
+int dense_key_words(int n); // u64 words of an action-id set (host-visible keys, root slot masks)
+bool dense_connected(const uint64_t *adj, int n);
+void dense_generate_roots(uint64_t seed, uint64_t epoch, uint64_t first_agent, int count, int n, int kmin, int kmax,
+                          uint32_t p24, uint64_t *adj, uint64_t *slots);
+
 } // namespace azd

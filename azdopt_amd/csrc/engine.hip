@@ -135,6 +135,9 @@ struct azd_engine {
     unsigned long long *d_log_key = nullptr;
     uint32_t *d_log_node = nullptr;
     int log_calls = 0;
+    // dense-graph space: host-visible key width (action-id sets) and the packed roots as the device wants them
+    int kw_host = 0;
+    std::vector<uint64_t> dense_packed;
     // pool step (agents multiplexed over searcher waves, evaluator workgroups on CUs of their own)
     bool pool_step = false;
     azd::PoolArgs pool{};         // device pointers of the queues
@@ -219,8 +222,71 @@ int sync_status(azd_engine *e) {
     return AZD_OK;
 }
 
+// dense-graph space: check the roots and hand the device what it works with -- the modifiable slots ranked by ACTION ID
+// (Add(e) = e for an absent edge, Delete(e) = E + e for a present one: adds first, each group ascending), as a
+// rank -> action id table, and the mask of ranks still open (all k of them)
+int upload_dense_roots(azd_engine *e, const uint8_t *adj_bytes, const uint64_t *slots) {
+    const Arenas &a = e->a;
+    const int n = a.n, E = a.E, KWH = e->kw_host;
+    const size_t per = 2 + MAX_NODE_ACTIONS / 4;
+    e->dense_packed.assign((size_t)a.B * per, 0ull);
+    for (int i = 0; i < a.B; ++i) {
+        uint64_t adj[64];
+        memcpy(adj, adj_bytes + (size_t)i * n * 8, (size_t)n * 8);
+        const uint64_t all = n >= 64 ? ~0ull : ((1ull << n) - 1ull);
+        for (int v = 0; v < n; ++v) {
+            if ((adj[v] & ~all) || ((adj[v] >> v) & 1ull)) {
+                g_last_error = "root graph: neighbour out of range or a loop";
+                return AZD_ERR_INVALID_ARGUMENT;
+            }
+            for (int u = 0; u < v; ++u)
+                if (((adj[v] >> u) & 1ull) != ((adj[u] >> v) & 1ull)) {
+                    g_last_error = "root graph: neighbourhoods are not symmetric";
+                    return AZD_ERR_INVALID_ARGUMENT;
+                }
+        }
+        if (!dense_connected(adj, n)) {
+            g_last_error = "root graph must be connected";
+            return AZD_ERR_INVALID_ARGUMENT;
+        }
+        const uint64_t *sl = slots + (size_t)i * KWH;
+        uint64_t *pk = &e->dense_packed[(size_t)i * per];
+        uint16_t *tab = reinterpret_cast<uint16_t *>(pk + 2);
+        for (int r = 0; r < MAX_NODE_ACTIONS; ++r) tab[r] = 0xFFFFu;
+        int k = 0;
+        for (int pass = 0; pass < 2; ++pass) { // adds (absent edges), then deletes (present edges)
+            int slot = 0;
+            for (int v = 1; v < n; ++v)
+                for (int u = 0; u < v; ++u, ++slot) {
+                    if (!((sl[slot >> 6] >> (slot & 63)) & 1ull)) continue;
+                    const bool present = (adj[v] >> u) & 1ull;
+                    if (present != (pass == 1)) continue;
+                    if (k >= MAX_NODE_ACTIONS) {
+                        g_last_error = "more modifiable slots than a node can hold (128)";
+                        return AZD_ERR_INVALID_ARGUMENT;
+                    }
+                    tab[k++] = (uint16_t)(pass == 0 ? slot : E + slot);
+                }
+        }
+        for (int w = 0; w < KWH; ++w) {
+            const int hi = E - 64 * w;
+            if ((hi <= 0 && sl[w] != 0) || (hi > 0 && hi < 64 && (sl[w] >> hi) != 0)) {
+                g_last_error = "slot mask has bits beyond the edge count";
+                return AZD_ERR_INVALID_ARGUMENT;
+            }
+        }
+        pk[0] = k >= 64 ? ~0ull : ((1ull << k) - 1ull);
+        pk[1] = k > 64 ? (k >= 128 ? ~0ull : ((1ull << (k - 64)) - 1ull)) : 0ull;
+    }
+    AZD_HIP(hipMemcpyAsync(e->d_stage_parents, adj_bytes, (size_t)a.B * n * 8, hipMemcpyHostToDevice, e->stream));
+    AZD_HIP(hipMemcpyAsync(e->d_stage_perm, e->dense_packed.data(), e->dense_packed.size() * 8, hipMemcpyHostToDevice, e->stream));
+    AZD_HIP(hipStreamSynchronize(e->stream)); // the packed block is pageable host memory
+    return AZD_OK;
+}
+
 int upload_roots(azd_engine *e, const uint8_t *parents, const uint64_t *permitted) {
     const Arenas &a = e->a;
+    if (a.space == SPACE_DENSE) return upload_dense_roots(e, parents, permitted);
     if (a.space == SPACE_RAMSEY) {
         // packed roots: colour of every edge in colex order (E bytes) + permitted edge positions
         for (int i = 0; i < a.B; ++i) {
@@ -335,6 +401,16 @@ int azd_ramsey_generate_roots(uint64_t seed, uint64_t epoch, uint64_t first_agen
     azd::ramsey_generate_roots(seed, epoch, first_agent, count, n, n_colors, kmin, kmax, colors, permitted);
     return AZD_OK;
 }
+int azd_dense_state_dim(int n) { return azd::dense_state_dim(n); }
+int azd_dense_action_dim(int n) { return azd::dense_action_dim(n); }
+int azd_dense_key_words(int n) { return azd::dense_key_words(n); }
+int azd_dense_generate_roots(uint64_t seed, uint64_t epoch, uint64_t first_agent, int count, int n, int kmin, int kmax, double p,
+                             uint64_t *adj, uint64_t *slots) {
+    if (!adj || !slots || count < 0 || n < 4 || n > AZD_DENSE_MAX_N || !(p > 0.0 && p <= 1.0)) return AZD_ERR_INVALID_ARGUMENT;
+    if (kmin < 1 || kmax < kmin || kmax > AZD_DENSE_MAX_SLOTS || kmax > azd::dense_edges(n)) return AZD_ERR_INVALID_ARGUMENT;
+    azd::dense_generate_roots(seed, epoch, first_agent, count, n, kmin, kmax, (uint32_t)(p * 16777216.0 + 0.5), adj, slots);
+    return AZD_OK;
+}
 int azd_c21_state_dim(int n) { return azd::c21_state_dim(n); }
 int azd_c21_action_dim(int n) { return azd::c21_action_dim(n); }
 int azd_c21_key_words(int n) { return azd::c21_key_words(n); }
@@ -438,7 +514,13 @@ uint64_t azd_evaluator_calls(azd_evaluator *ev) { return ev ? ev->calls : 0; }
 int azd_engine_create(azd_engine **out, const azd_engine_config *cfg, azd_evaluator *ev) {
     if (!out || !cfg) return AZD_ERR_INVALID_ARGUMENT;
     const bool ramsey = cfg->space_id == AZD_SPACE_RAMSEY;
-    if (ramsey) {
+    const bool dense = cfg->space_id == AZD_SPACE_DENSE;
+    if (dense) {
+        if (cfg->n < 4 || cfg->n > AZD_DENSE_MAX_N || cfg->batch <= 0 || cfg->layers > 1) {
+            azd::g_last_error = "unsupported dense-graph space (need 4 <= n <= 64, no Layered wrapper)";
+            return AZD_ERR_INVALID_ARGUMENT;
+        }
+    } else if (ramsey) {
         bool ok = cfg->batch > 0 && cfg->n >= 3 && cfg->n <= AZD_RAMSEY_MAX_N && cfg->n_colors >= 2 && cfg->n_colors <= 4;
         if (ok) {
             for (int c = 0; c < cfg->n_colors; ++c) ok = ok && cfg->clique_sizes[c] >= 2 && cfg->clique_sizes[c] <= 5;
@@ -471,10 +553,17 @@ int azd_engine_create(azd_engine **out, const azd_engine_config *cfg, azd_evalua
     memset(&a, 0, sizeof(a));
     a.n = cfg->n;
     a.B = cfg->batch;
-    a.space = ramsey ? azd::SPACE_RAMSEY : azd::SPACE_C21;
+    a.space = dense ? azd::SPACE_DENSE : ramsey ? azd::SPACE_RAMSEY : azd::SPACE_C21;
     a.path_kind = cfg->path_kind;
     a.layers = cfg->layers > 1 ? cfg->layers : 1;
-    if (ramsey) {
+    if (dense) {
+        a.E = azd::dense_edges(cfg->n);
+        a.A = azd::dense_action_dim(cfg->n);
+        a.S = azd::dense_state_dim(cfg->n);
+        a.KW = 2; // device keys: ranks of the root's (at most 128) modifiable slots
+        a.eval_slope = azd::c21_eval_slope(cfg->n);
+        e->kw_host = azd::dense_key_words(cfg->n);
+    } else if (ramsey) {
         a.C = cfg->n_colors;
         a.E = azd::ramsey_edges(cfg->n);
         a.A = azd::ramsey_action_dim(cfg->n, a.C);
@@ -545,6 +634,12 @@ int azd_engine_create(azd_engine **out, const azd_engine_config *cfg, azd_evalua
     TRY(e->alloc(&a.argmin, 1));
     TRY(e->alloc(&a.status, 1));
     if (a.layers > 1) TRY(e->alloc(&a.cur_seq, B * azd::MAX_NODE_ACTIONS));
+    if (dense) {
+        TRY(e->alloc(&a.root_adj, B * 64));
+        TRY(e->alloc(&a.cur_adj, B * 64));
+        TRY(e->alloc(&a.root_aid, B * azd::MAX_NODE_ACTIONS));
+        TRY(e->alloc(&a.argmin_d, 1));
+    }
     if (ramsey) {
         TRY(e->alloc(&a.root_nbr, B * 128));
         TRY(e->alloc(&a.cur_nbr, B * 128));
@@ -592,8 +687,8 @@ int azd_engine_create(azd_engine **out, const azd_engine_config *cfg, azd_evalua
         TRY(e->alloc(&e->d_log_key, (size_t)e->log_calls * n_wg));
         TRY(e->alloc(&e->d_log_node, (size_t)e->log_calls * n_wg));
     }
-    TRY(e->alloc(&e->d_stage_parents, B * (size_t)(ramsey ? a.E : a.n)));
-    TRY(e->alloc(&e->d_stage_perm, B * a.KW));
+    TRY(e->alloc(&e->d_stage_parents, B * (size_t)(dense ? 8 * a.n : ramsey ? a.E : a.n)));
+    TRY(e->alloc(&e->d_stage_perm, B * (size_t)(dense ? 2 + azd::MAX_NODE_ACTIONS / 4 : a.KW)));
     {
         hipError_t he = hipHostMalloc((void **)&e->h_status, sizeof(azd::StatusRec));
         if (he == hipSuccess) he = hipHostMalloc((void **)&e->h_argmin, sizeof(azd::ArgminRec));
@@ -969,6 +1064,10 @@ int azd_engine_par_reset_trees(azd_engine *e, const uint8_t *parents, const uint
 // device: no host round trip at the epoch boundary.
 static int c21_policy_args_ok(azd_engine *e, int kmin, int kmax) {
     if (!e || !e->initialised) return AZD_ERR_INVALID_ARGUMENT;
+    if (e->a.space == azd::SPACE_DENSE) {
+        azd::g_last_error = "the device root policy is not built for the dense-graph space: pass new roots to par_reset_trees";
+        return AZD_ERR_UNSUPPORTED;
+    }
     if (e->a.path_kind == azd::PATH_SEQUENCE && e->a.node_cap > 4096) {
         azd::g_last_error = "the device root policy handles sequence-keyed trees of at most 4096 nodes";
         return AZD_ERR_UNSUPPORTED;
@@ -1026,6 +1125,15 @@ int azd_engine_ramsey_argmin_data(azd_engine *e, azd_ramsey_argmin *out) {
     static_assert(sizeof(azd_ramsey_argmin) == sizeof(azd::RamseyArgminRec), "ABI struct mismatch");
     AZD_HIP(hipStreamSynchronize(e->stream));
     AZD_HIP(hipMemcpy(out, e->a.argmin_r, sizeof(azd_ramsey_argmin), hipMemcpyDeviceToHost));
+    return AZD_OK;
+}
+int azd_engine_dense_argmin_data(azd_engine *e, azd_dense_argmin *out) {
+    if (!e || !out || !e->initialised) return AZD_ERR_INVALID_ARGUMENT;
+    if (e->a.space != azd::SPACE_DENSE) return AZD_ERR_UNSUPPORTED;
+    AZD_HIP(hipSetDevice(e->cfg.device));
+    static_assert(sizeof(azd_dense_argmin) == sizeof(azd::DenseArgminRec), "ABI struct mismatch");
+    AZD_HIP(hipStreamSynchronize(e->stream));
+    AZD_HIP(hipMemcpy(out, e->a.argmin_d, sizeof(azd_dense_argmin), hipMemcpyDeviceToHost));
     return AZD_OK;
 }
 int azd_engine_ramsey_agent_counts(azd_engine *e, int agent, int32_t *counts, int32_t *totals) {
@@ -1093,7 +1201,16 @@ int azd_engine_export_tree(azd_engine *e, int agent, float *c, float *c_star, ui
     AZD_HIP(hipMemcpy(nodes.data(), a.nodes + (size_t)agent * a.node_cap, nodes.size() * sizeof(azd::NodeRec), hipMemcpyDeviceToHost));
     if (na) AZD_HIP(hipMemcpy(arcs.data(), a.arcs + (size_t)agent * a.arc_cap, arcs.size() * sizeof(azd::ArcRec), hipMemcpyDeviceToHost));
     if (np) AZD_HIP(hipMemcpy(preds.data(), a.preds + (size_t)agent * a.pred_cap, preds.size() * sizeof(azd::PredRec), hipMemcpyDeviceToHost));
-    if (keys) AZD_HIP(hipMemcpy(keys, a.keys + (size_t)agent * a.node_cap * a.KW, (size_t)nn * a.KW * 8, hipMemcpyDeviceToHost));
+    if (keys && a.space == azd::SPACE_DENSE) { // device keys are sets of RANKS: back to action-id sets (kw_host words per node)
+        std::vector<uint64_t> rk((size_t)nn * 2);
+        uint16_t tab[azd::MAX_NODE_ACTIONS];
+        AZD_HIP(hipMemcpy(rk.data(), a.keys + (size_t)agent * a.node_cap * 2, rk.size() * 8, hipMemcpyDeviceToHost));
+        AZD_HIP(hipMemcpy(tab, a.root_aid + (size_t)agent * azd::MAX_NODE_ACTIONS, sizeof(tab), hipMemcpyDeviceToHost));
+        memset(keys, 0, (size_t)nn * e->kw_host * 8);
+        for (int i = 0; i < nn; ++i)
+            for (int r = 0; r < azd::MAX_NODE_ACTIONS; ++r)
+                if ((rk[(size_t)i * 2 + (r >> 6)] >> (r & 63)) & 1ull) keys[(size_t)i * e->kw_host + (tab[r] >> 6)] |= 1ull << (tab[r] & 63);
+    } else if (keys) AZD_HIP(hipMemcpy(keys, a.keys + (size_t)agent * a.node_cap * a.KW, (size_t)nn * a.KW * 8, hipMemcpyDeviceToHost));
     for (int i = 0; i < nn; ++i) {
         if (c) c[i] = nodes[(size_t)i].c;
         if (c_star) c_star[i] = nodes[(size_t)i].c_star;
@@ -1121,6 +1238,27 @@ int azd_engine_agent_state(azd_engine *e, int agent, uint8_t *parents, uint64_t 
     AZD_HIP(hipSetDevice(e->cfg.device));
     AZD_HIP(hipStreamSynchronize(e->stream));
     const azd::Arenas &a = e->a;
+    if (a.space == azd::SPACE_DENSE) { // `parents` receives the neighbourhoods (8 n bytes); masks are kw_host words
+        uint16_t tab[azd::MAX_NODE_ACTIONS];
+        uint64_t rem[2], pth[2];
+        AZD_HIP(hipMemcpy(tab, a.root_aid + (size_t)agent * azd::MAX_NODE_ACTIONS, sizeof(tab), hipMemcpyDeviceToHost));
+        AZD_HIP(hipMemcpy(rem, a.cur_perm + (size_t)agent * 2, 16, hipMemcpyDeviceToHost));
+        AZD_HIP(hipMemcpy(pth, a.cur_path + (size_t)agent * 2, 16, hipMemcpyDeviceToHost));
+        if (parents) AZD_HIP(hipMemcpy(parents, a.cur_adj + (size_t)agent * 64, (size_t)a.n * 8, hipMemcpyDeviceToHost));
+        if (permitted) memset(permitted, 0, (size_t)e->kw_host * 8);
+        if (path) memset(path, 0, (size_t)e->kw_host * 8);
+        for (int r = 0; r < azd::MAX_NODE_ACTIONS; ++r) {
+            if (permitted && ((rem[r >> 6] >> (r & 63)) & 1ull)) { // open SLOTS, as in the packed root
+                const int slot = tab[r] % a.E;
+                permitted[slot >> 6] |= 1ull << (slot & 63);
+            }
+            if (path && ((pth[r >> 6] >> (r & 63)) & 1ull)) path[tab[r] >> 6] |= 1ull << (tab[r] & 63);
+        }
+        if (state_pos) AZD_HIP(hipMemcpy(state_pos, a.state_pos + agent, 4, hipMemcpyDeviceToHost));
+        if (lambda_1) AZD_HIP(hipMemcpy(lambda_1, a.cur_lambda + agent, 8, hipMemcpyDeviceToHost));
+        if (matching_size) AZD_HIP(hipMemcpy(matching_size, a.cur_mu + agent, 4, hipMemcpyDeviceToHost));
+        return AZD_OK;
+    }
     if (a.space == azd::SPACE_RAMSEY) { // `parents` receives the colour of every edge (E bytes)
         uint32_t nbr[128];
         AZD_HIP(hipMemcpy(nbr, a.cur_nbr + (size_t)agent * 128, sizeof(nbr), hipMemcpyDeviceToHost));

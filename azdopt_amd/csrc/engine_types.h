@@ -21,7 +21,7 @@ constexpr int PARENTS_STRIDE = 32; // bytes per packed parents row on the device
 constexpr int MAX_N = 24;
 constexpr int MAX_KW = 6;                   // c21 uses up to 4 key words, the Ramsey space up to 6
 constexpr int PATH_SET = 0, PATH_SEQUENCE = 1;   // = AZD_PATH_*
-constexpr int SPACE_C21 = 1, SPACE_RAMSEY = 2; // = AZD_SPACE_* of include/azdopt_amd.h
+constexpr int SPACE_C21 = 1, SPACE_RAMSEY = 2, SPACE_DENSE = 3; // = AZD_SPACE_* of include/azdopt_amd.h
 constexpr int PRED_CHUNKS = 2;               // a node holds at most 64*PRED_CHUNKS legal actions
 constexpr int MAX_NODE_ACTIONS = 64 * PRED_CHUNKS;
 constexpr int FRONTIER_CAP = 256;            // LDS-staged cascade frontier per tree
@@ -87,6 +87,16 @@ struct RamseyArgminRec { // device copy of azd_ramsey_argmin
     uint32_t node;
 };
 
+struct DenseArgminRec { // device copy of azd_dense_argmin
+    uint64_t adj[64];
+    uint64_t permitted[40]; // modifiable slots (colex positions) still open
+    double lambda_1;
+    int32_t matching_size;
+    float eval;
+    int32_t agent;
+    uint32_t node;
+};
+
 struct StatusRec { // small device block copied back after every host-visible call
     unsigned long long improved;   // k_argmin calls that improved the argmin
     unsigned long long expansions; // sum over agents and calls (metric numerator)
@@ -132,6 +142,11 @@ struct Arenas {
     int32_t *root_counts, *cur_counts; // [B][C*E]
     int32_t *root_tot, *cur_tot;       // [B][4]
     RamseyArgminRec *argmin_r;
+    // ---- dense-graph space (space_dense.inc); null for the other spaces.  E = N(N-1)/2 edge slots, A = 2E, S = 3E + 1,
+    // KW = 2 (keys over the ranks of the root's modifiable slots)
+    uint64_t *root_adj, *cur_adj; // [B][64] neighbourhood bitsets
+    uint16_t *root_aid;           // [B][MAX_NODE_ACTIONS] rank -> action id, ascending (0xFFFF beyond the root's k slots)
+    DenseArgminRec *argmin_d;
     // ---- path encoding P (az-discrete-opt/src/path/): PATH_SET = ActionSet (= ActionMultiset on
     // ActionsNeverRepeat spaces), PATH_SEQUENCE = ActionSequence (= OrderedActionSet): no transpositions
     int path_kind;
@@ -234,6 +249,14 @@ bool ramsey_pool_plan(const Arenas &a, const FusedEval &ev, PoolArgs *pool, uint
 void ramsey_launch_pool(const Arenas &a, const PersistArgs *d_args, int n_calls, unsigned long long *log_key, const float *params,
                         const void *wpk, int n_blocks, uint32_t dyn_stride, size_t dyn_bytes, void *stream);
 void launch_probe_xcc(uint32_t *d_out, int n_blocks, void *stream); // HW_REG_XCC_ID of every block of a launch (tests)
+
+// the launch-per-phase kernels for SPACE_DENSE (dense_kernels.hip); the c21 entry points forward to them.  The space's
+// state vector (3E + 1 floats) does not fit the CU-resident forms' LDS plans: it runs one launch per phase.
+void dense_launch_init_roots(const Arenas &a, const uint8_t *d_adj, const uint64_t *d_packed, void *stream);
+void dense_launch_add_actions(const Arenas &a, int root_mode, void *stream);
+void dense_launch_rollout(const Arenas &a, const TolTable &tol, void *stream);
+void dense_launch_argmin(const Arenas &a, int init_mode, void *stream);
+void dense_launch_observe(const Arenas &a, uint32_t n_obs_tol, void *stream);
 void launch_persist(const Arenas &a, const PersistArgs *d_args, int n_calls, unsigned long long *log_key,
                     uint32_t *log_node, uint32_t dyn_stride, size_t dyn_bytes, void *stream);
 void launch_c21_modify_roots(const Arenas &a, uint64_t seed, uint64_t epoch, uint64_t first_agent, int kmin, int kmax,

@@ -63,6 +63,10 @@ void launch_probe_xcc(uint32_t *d_out, int n_blocks, void *stream) {
 bool pool_plan(const Arenas &a, const FusedEval &ev, PoolArgs *pool, uint32_t *dyn_stride, size_t *dyn_bytes, const char **why) {
     const char *dummy;
     if (!why) why = &dummy;
+    if (a.space == SPACE_DENSE) {
+        *why = "dense-graph space: launch-per-phase form only (its state vector does not fit the CU-resident forms)";
+        return false;
+    }
     if (a.space == SPACE_RAMSEY) return ramsey_pool_plan(a, ev, pool, dyn_stride, dyn_bytes, why);
     return pool_plan_common(a, ev, pool, dyn_stride, dyn_bytes, why, C21Space<1>::pool_dyn_bytes(a), sizeof(WaveLds));
 }
@@ -89,6 +93,10 @@ void launch_async(const Arenas &a, const PersistArgs *d_args, int n_calls, unsig
 bool async_plan(const Arenas &a, const FusedEval &ev, uint32_t *dyn_stride, size_t *dyn_bytes, const char **why) {
     const char *dummy;
     if (!why) why = &dummy;
+    if (a.space == SPACE_DENSE) {
+        *why = "dense-graph space: launch-per-phase form only (its state vector does not fit the CU-resident forms)";
+        return false;
+    }
     if (a.space == SPACE_RAMSEY) return ramsey_async_plan(a, ev, dyn_stride, dyn_bytes, why);
     if (ev.kind == 3)
         for (int l = 0; l < ev.n_layers; ++l)
@@ -186,22 +194,27 @@ static void l_observe(const Arenas &a, uint32_t tol, hipStream_t st) {
 
 void launch_init_roots(const Arenas &a, const uint8_t *d_parents, const uint64_t *d_permitted, void *stream) {
     if (a.space == SPACE_RAMSEY) return ramsey_launch_init_roots(a, d_parents, d_permitted, stream);
+    if (a.space == SPACE_DENSE) return dense_launch_init_roots(a, d_parents, d_permitted, stream);
     DISPATCH_KW(a, l_init_roots, a, d_parents, d_permitted, (hipStream_t)stream);
 }
 void launch_add_actions(const Arenas &a, int root_mode, void *stream) {
     if (a.space == SPACE_RAMSEY) return ramsey_launch_add_actions(a, root_mode, stream);
+    if (a.space == SPACE_DENSE) return dense_launch_add_actions(a, root_mode, stream);
     DISPATCH_KW(a, l_add_actions, a, root_mode, (hipStream_t)stream);
 }
 void launch_rollout(const Arenas &a, const TolTable &tol, void *stream) {
     if (a.space == SPACE_RAMSEY) return ramsey_launch_rollout(a, tol, stream);
+    if (a.space == SPACE_DENSE) return dense_launch_rollout(a, tol, stream);
     DISPATCH_KW(a, l_rollout, a, tol, (hipStream_t)stream);
 }
 void launch_argmin(const Arenas &a, int init_mode, void *stream) {
     if (a.space == SPACE_RAMSEY) return ramsey_launch_argmin(a, init_mode, stream);
+    if (a.space == SPACE_DENSE) return dense_launch_argmin(a, init_mode, stream);
     DISPATCH_KW(a, l_argmin, a, init_mode, (hipStream_t)stream);
 }
 void launch_observe(const Arenas &a, uint32_t n_obs_tol, void *stream) {
     if (a.space == SPACE_RAMSEY) return ramsey_launch_observe(a, n_obs_tol, stream);
+    if (a.space == SPACE_DENSE) return dense_launch_observe(a, n_obs_tol, stream);
     DISPATCH_KW(a, l_observe, a, n_obs_tol, (hipStream_t)stream);
 }
 template <class SP>
@@ -221,6 +234,10 @@ bool persist_plan(const Arenas &a, const FusedEval &ev, uint32_t *dyn_stride, si
     if (!why) why = &dummy;
     size_t stride = (dyn_lds_bytes(a.n) + 15) & ~(size_t)15;
     size_t total = stride * PERSIST_WAVES;
+    if (a.space == SPACE_DENSE) {
+        *why = "dense-graph space: launch-per-phase form only (its state vector does not fit the CU-resident forms)";
+        return false;
+    }
     if (a.space == SPACE_RAMSEY) return ramsey_persist_plan(a, ev, dyn_stride, dyn_bytes, why);
     if (ev.kind == 3) {
         if (ev.bf16) { // bf16 weight storage is built into the asynchronous step only

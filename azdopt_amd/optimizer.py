@@ -29,6 +29,17 @@ class RamseyArgminData:
         self.agent, self.node = rec.agent, rec.node
 
 
+class DenseArgminData:
+    """az-discrete-opt/src/log.rs:1-11 for the dense-graph space: state = neighbourhoods + open slots,
+    cost = Conjecture2Dot1Cost {lambda_1, matching number}"""
+
+    def __init__(self, rec, space):
+        self.state = dict(adj=np.array(rec.adj[:space.n], np.uint64), permitted=np.array(rec.permitted[:space.KEY_WORDS], np.uint64))
+        self.cost = dict(lambda_1=rec.lambda_1, matching=[None] * rec.matching_size)  # the matching itself is not constructed
+        self.eval = np.float32(rec.eval)
+        self.agent, self.node = rec.agent, rec.node
+
+
 class TreeView:
     """Raw arrays of one SearchTree (tree/mod.rs:28-32): nodes, arcs, predictions, keys."""
     FIELDS = ("c", "c_star", "n_t", "exhausted", "act_begin", "act_end", "keys", "e_src", "e_dst", "e_pp",
@@ -154,6 +165,10 @@ class NablaOptimizer:
             rec = _lib.RamseyArgmin()
             _lib.check(self._L.azd_engine_ramsey_argmin_data(self._h, C.byref(rec)), "ramsey_argmin_data")
             return RamseyArgminData(rec, self.space)
+        if self.space.SPACE_ID == _lib.SPACE_DENSE:
+            rec = _lib.DenseArgmin()
+            _lib.check(self._L.azd_engine_dense_argmin_data(self._h, C.byref(rec)), "dense_argmin_data")
+            return DenseArgminData(rec, self.space)
         rec = _lib.Argmin()
         _lib.check(self._L.azd_engine_argmin_data(self._h, C.byref(rec)), "argmin_data")
         return ArgminData(rec, self.space.n, self.space.KEY_WORDS)

@@ -148,6 +148,49 @@ class RamseySpaceNoEdgeRecolor(ActionsNeverRepeat, ActionOrderIndependent):
         return index % self.E, index // self.E
 
 
+class DenseGraphSpace(ActionsNeverRepeat, ActionOrderIndependent):
+    """Connected graphs on N <= 64 vertices; an action adds an absent edge or deletes a present non-cut edge, every edge
+    slot at most once (BASELINE configs[4], N = 50).  BUILD-DEFINED: the reference has the pieces
+    (connected_bitset_graph/mod.rs: is_cut_edge, action_kinds, conjecture_2_1_cost; bitset_graph/space/action.rs:
+    AddOrDeleteEdge indexing; 05-ah.rs:39-40: STATE = E + ACTION + 1) but no live NablaStateActionSpace over general
+    graphs; the definition is in oracle/dense_graph.inc.  cost = Conjecture2Dot1Cost {lambda_1, matching number};
+    evaluate = squish(mu + lambda_1) with the bounds of 04-c21-tree.rs:58-74; at most 128 modifiable slots per root."""
+
+    SPACE_ID = _lib.SPACE_DENSE
+    MAX_SLOTS = 128
+
+    def __init__(self, n, p=0.2):
+        self.n, self.p = int(n), float(p)
+        self.E = self.n * (self.n - 1) // 2
+        L = _lib.lib()
+        self.STATE_DIM = L.azd_dense_state_dim(self.n)
+        self.ACTION_DIM = L.azd_dense_action_dim(self.n)
+        self.KEY_WORDS = L.azd_dense_key_words(self.n)
+
+    @property
+    def ROOT_BYTES(self):
+        return 8 * self.n
+
+    def default_permitted_range(self):
+        hi = min(self.MAX_SLOTS, self.E // 2)
+        return min(5, hi), hi
+
+    def generate_roots(self, seed, count, first_agent=0, epoch=0, kmin=None, kmax=None):
+        """seeded `init_states`: (adj u64 [count, n] viewed as bytes [count, 8 n], modifiable slots u64 [count, KEY_WORDS])"""
+        lo, hi = self.default_permitted_range()
+        kmin = lo if kmin is None else kmin
+        kmax = hi if kmax is None else kmax
+        adj = np.zeros((count, self.n), np.uint64)
+        slots = np.zeros((count, self.KEY_WORDS), np.uint64)
+        _lib.check(_lib.lib().azd_dense_generate_roots(seed, epoch, first_agent, count, self.n, kmin, kmax, self.p,
+                                                       _lib.ptr(adj), _lib.ptr(slots)), "azd_dense_generate_roots")
+        return adj.view(np.uint8).reshape(count, 8 * self.n), slots
+
+    def action(self, index):
+        """("add" | "delete", edge slot) of action `index` (AddOrDeleteEdge::from_action_index, action.rs:20-27)"""
+        return ("add", index) if index < self.E else ("delete", index - self.E)
+
+
 class Layered:
     """Layered<LAYERS, Space> (az-discrete-opt/src/space/layered.rs:3-20; trait impl nabla/space/mod.rs:41-111):
     the evaluator sees the last `layers` states of the path.  STATE_DIM = layers * inner STATE_DIM; every other

@@ -88,6 +88,27 @@ int azd_ramsey_generate_roots(uint64_t seed, uint64_t epoch, uint64_t first_agen
                               int n_colors, int kmin, int kmax, uint8_t *colors, uint64_t *permitted);
 
 /* ------------------------------------------------------------------------- */
+/* Space seam: dense graphs (BUILD-DEFINED: the reference has no live         */
+/*   NablaStateActionSpace over general graphs, examples/05-ah.rs is a stub)  */
+/*   built from ConnectedBitsetGraph (connected_bitset_graph/mod.rs:45-71,    */
+/*   139-158, 226-338), AddOrDeleteEdge (bitset_graph/space/action.rs:4-27)   */
+/*   and the STATE = E + ACTION + 1 hint (05-ah.rs:39-40); definition in      */
+/*   oracle/dense_graph.inc.  BASELINE.json configs[4]: N = 50.               */
+/* ------------------------------------------------------------------------- */
+#define AZD_SPACE_DENSE 3
+#define AZD_DENSE_MAX_N 64
+#define AZD_DENSE_MAX_SLOTS 128 /* modifiable edge slots of a root = legal actions a node can hold */
+int azd_dense_state_dim(int n);  /* 3E + 1 */
+int azd_dense_action_dim(int n); /* 2E: Add(e) = e, Delete(e) = E + e */
+int azd_dense_key_words(int n);  /* u64 words of an action-id set */
+/* Seeded `init_states`: a connected G(n, p) (redrawn until connected, as ConnectedBitsetGraph::generate does) and
+ * k in [kmin, kmax] modifiable edge slots.  Packed root format of this space:
+ *   adj   [count][n]  u64  neighbourhood bitsets (passed as the `parents` bytes of the engine calls: 8 n bytes per root)
+ *   slots [count][KW] u64  bit e set <=> the edge slot at colex position e may be modified (once) */
+int azd_dense_generate_roots(uint64_t seed, uint64_t epoch, uint64_t first_agent, int count, int n, int kmin, int kmax,
+                             double p, uint64_t *adj, uint64_t *slots);
+
+/* ------------------------------------------------------------------------- */
 /* Evaluator seam (NablaModel)                                               */
 /* ------------------------------------------------------------------------- */
 typedef struct azd_evaluator azd_evaluator;
@@ -227,6 +248,17 @@ typedef struct azd_ramsey_argmin {
     uint32_t node;
 } azd_ramsey_argmin;
 
+/* ArgminData for the dense-graph space: the graph, its open slots, Conjecture2Dot1Cost */
+typedef struct azd_dense_argmin {
+    uint64_t adj[64];
+    uint64_t permitted[40];    /* edge slots still modifiable */
+    double lambda_1;
+    int32_t matching_size;
+    float eval;
+    int32_t agent;
+    uint32_t node;
+} azd_dense_argmin;
+
 enum { /* indices into azd_engine_counters' output */
     AZD_CTR_EXPANSIONS = 0,     /* calls that ended on a new non-terminal node (metric numerator) */
     AZD_CTR_TERMINALS = 1,
@@ -292,6 +324,7 @@ int azd_engine_par_reset_trees(azd_engine *e, const uint8_t *parents, const uint
 /* NablaOptimizer::argmin_data (optimizer/mod.rs:361) */
 int azd_engine_argmin_data(azd_engine *e, azd_argmin *out);
 int azd_engine_ramsey_argmin_data(azd_engine *e, azd_ramsey_argmin *out); /* AZD_SPACE_RAMSEY engines */
+int azd_engine_dense_argmin_data(azd_engine *e, azd_dense_argmin *out);   /* AZD_SPACE_DENSE engines */
 /* the agent's live per-edge clique counts [C][E] and totals [4] (RamseyCounts, mod.rs:12-17) */
 int azd_engine_ramsey_agent_counts(azd_engine *e, int agent, int32_t *counts, int32_t *totals);
 

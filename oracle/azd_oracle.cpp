@@ -33,7 +33,7 @@ namespace {
 
 constexpr int MAXN = 32;
 constexpr int MAXC = 4;   /* colours of the Ramsey space */
-constexpr int SPACE_C21 = 0, SPACE_RAMSEY = 1;
+constexpr int SPACE_C21 = 0, SPACE_RAMSEY = 1, SPACE_DENSE = 2;
 constexpr uint32_t NONE = 0xFFFFFFFFu;
 
 /* ------------------------------------------------------------------ */
@@ -105,6 +105,7 @@ struct State {
     uint8_t parents[MAXN];
     std::set<uint32_t> permitted; /* BTreeSet<usize> */
     uint32_t nbr[MAXC][MAXN];
+    uint64_t adj[64]; /* dense-graph space (dense_graph.inc): ConnectedBitsetGraph<N, B64>::neighborhoods; `permitted` = remaining slots */
     std::vector<int32_t> counts;
     int32_t total[MAXC];
     /* Layered<L, Space> (az-discrete-opt/src/space/layered.rs, nabla/space/mod.rs:41-111): the state is
@@ -116,6 +117,7 @@ struct State {
 struct Cost { /* Conjecture2Dot1Cost, connected_bitset_graph/mod.rs:340-344; TotalCounts<C>, ramsey_counts/mod.rs:192-193 */
     double lambda1 = 0.0;
     std::vector<std::pair<int, int>> matching;
+    int mu = 0; /* dense-graph space: the matching number (the matching itself is not constructed) */
     int32_t totals[MAXC] = {0, 0, 0, 0};
 };
 
@@ -257,6 +259,8 @@ float c21_eval(int n, double lambda1, int matching_size) {
     return slope * x;
 }
 
+#include "dense_graph.inc"
+
 /* ------------------------------------------------------------------ */
 /* Ramsey space primitives                                             */
 /* ------------------------------------------------------------------ */
@@ -353,6 +357,14 @@ struct Space {
             s.older.push_back(std::move(prev));
             if ((int)s.older.size() > layers - 1) s.older.erase(s.older.begin()); /* the ring drops its oldest */
         }
+        if (kind == SPACE_DENSE) { /* AddOrDeleteEdge::from_action_index (action.rs:20-27); add_or_remove_edge_unchecked */
+            int slot = index % E, mx, mn;
+            from_colex_position(slot, &mx, &mn);
+            s.adj[mx] ^= 1ull << mn;
+            s.adj[mn] ^= 1ull << mx;
+            s.permitted.erase((uint32_t)slot); /* every slot at most once */
+            return;
+        }
         if (kind == SPACE_RAMSEY) {
             int edge_pos = index % E, new_color = index / E; /* `action`, :48-54 */
             ramsey_reassign_color(s, C, E, sizes, edge_pos, new_color);
@@ -374,6 +386,22 @@ struct Space {
      * a_id = e_pos + new_color * E; `r` receives the reward hint folded to the f32
      * r_sa = old_count * w[old] - new_count * w[new] of g_theta_star_sa (:163-165). */
     void action_data(const State &s, std::vector<uint32_t> &out, std::vector<float> *r = nullptr) const {
+        if (kind == SPACE_DENSE) { /* action_kinds (mod.rs:139-158) over the remaining slots, ascending action id */
+            out.clear();
+            if (r) r->clear();
+            for (uint32_t slot : s.permitted) { /* Add(e) = e */
+                int mx, mn;
+                from_colex_position((int)slot, &mx, &mn);
+                if (!dense_has_edge(s.adj, mx, mn)) out.push_back(slot);
+            }
+            for (uint32_t slot : s.permitted) { /* Delete(e) = E + e, unless e is a cut edge */
+                int mx, mn;
+                from_colex_position((int)slot, &mx, &mn);
+                if (dense_has_edge(s.adj, mx, mn) && !dense_is_cut_edge(s.adj, mx, mn)) out.push_back((uint32_t)E + slot);
+            }
+            if (r) r->assign(out.size(), 0.f);
+            return;
+        }
         if (kind == SPACE_RAMSEY) {
             out.clear();
             if (r) r->clear();
@@ -421,6 +449,18 @@ struct Space {
     void write_vec_inner(const State &s, float *v) const {
         const int S = S_inner;
         for (int i = 0; i < S; ++i) v[i] = 0.f;
+        if (kind == SPACE_DENSE) { /* dense_graph.inc header: edge bools, modifiable absent, modifiable present, remaining / E */
+            int pos = 0;
+            for (int x = 0; x < n; ++x)
+                for (int u = 0; u < x; ++u, ++pos) v[pos] = dense_has_edge(s.adj, x, u) ? 1.0f : 0.f;
+            for (uint32_t slot : s.permitted) {
+                int mx, mn;
+                from_colex_position((int)slot, &mx, &mn);
+                v[(dense_has_edge(s.adj, mx, mn) ? 2 * E : E) + (int)slot] = 1.f;
+            }
+            v[3 * E] = (float)s.permitted.size() / (float)E;
+            return;
+        }
         if (kind == SPACE_RAMSEY) { /* ramsey_counts/space.rs:122-153 */
             for (int i = 0; i < C * E; ++i) v[i] = (float)s.counts[i];
             for (int c = 0; c < C; ++c) {
@@ -441,6 +481,11 @@ struct Space {
      * full = true: the ArgminData cost reported to the user (full f64 bracket) */
     Cost cost(const State &s, bool full = false) const {
         Cost c;
+        if (kind == SPACE_DENSE) { /* conjecture_2_1_cost, mod.rs:319-338 */
+            c.lambda1 = dense_lambda1(s.adj, n);
+            c.mu = dense_matching_tutte(s.adj, n);
+            return c;
+        }
         if (kind == SPACE_RAMSEY) { /* ramsey_counts/space.rs:155-157 */
             for (int i = 0; i < C; ++i) c.totals[i] = s.total[i];
             return c;
@@ -455,6 +500,7 @@ struct Space {
             for (int i = 0; i < C; ++i) sum = sum + (float)c.totals[i] * weights[i];
             return sum;
         }
+        if (kind == SPACE_DENSE) return c21_eval(n, c.lambda1, c.mu); /* the same squish with N's bounds */
         return c21_eval(n, c.lambda1, (int)c.matching.size());
     }
     /* 04-c21-tree.rs:103; ramsey_counts/space.rs:167-172 */
@@ -794,6 +840,14 @@ namespace {
 void unpack_state(const Space &sp, const uint8_t *parents, const uint64_t *permitted, State &s) {
     s.older.clear(); /* Layers::new(s): a ring of one */
     std::memset(s.parents, 0, sizeof(s.parents));
+    if (sp.kind == SPACE_DENSE) { /* packed root: neighbourhoods as n u64 (8 n bytes) + modifiable slots (E bits) */
+        std::memset(s.adj, 0, sizeof(s.adj));
+        std::memcpy(s.adj, parents, (size_t)sp.n * 8);
+        s.permitted.clear();
+        for (int e = 0; e < sp.E; ++e)
+            if ((permitted[e >> 6] >> (e & 63)) & 1ull) s.permitted.insert((uint32_t)e);
+        return;
+    }
     if (sp.kind == SPACE_RAMSEY) {
         std::memset(s.nbr, 0, sizeof(s.nbr));
         int pos = 0;
@@ -815,7 +869,8 @@ void unpack_state(const Space &sp, const uint8_t *parents, const uint64_t *permi
         if ((permitted[a >> 6] >> (a & 63)) & 1ull) s.permitted.insert((uint32_t)a);
 }
 void pack_state(const Space &sp, const State &s, uint8_t *parents, uint64_t *permitted) {
-    if (sp.kind == SPACE_RAMSEY) {
+    if (sp.kind == SPACE_DENSE) std::memcpy(parents, s.adj, (size_t)sp.n * 8);
+    else if (sp.kind == SPACE_RAMSEY) {
         int pos = 0;
         for (int v = 0; v < sp.n; ++v)
             for (int u = 0; u < v; ++u, ++pos) parents[pos] = (uint8_t)edge_color(s, sp.C, v, u);
@@ -957,6 +1012,44 @@ void orc_gen_ramsey_roots(uint64_t seed, uint64_t epoch, uint64_t first_agent, i
         gen_ramsey_root(seed, domain, agent, E, n_colors, KW, k, colors + (size_t)i * E, permitted + (size_t)i * KW);
     }
 }
+/* Root generator spec (stands in for ConnectedBitsetGraph::generate(p), mod.rs:84-97, which redraws G(n, p) until it is
+ * connected, + a permitted-slot set in the image of modify_parent_once.rs:14-25), seeded:
+ *   stream(i) = key4(seed, DOMAIN_ROOT ^ (epoch << 32), agent, i)
+ *   k = kmin + below(stream(0), kmax - kmin + 1)
+ *   attempt t = 0, 1, ...: edge at slot e present iff (stream(4096 + t E + e) >> 40) < p24 (p24 = p * 2^24); first connected
+ *   permitted slots = first k of the Fisher-Yates shuffle of 0..E-1 (draws 64 + j, as for the other spaces) */
+static void gen_dense_root(uint64_t seed, uint64_t domain, uint64_t agent, int n, int k, uint32_t p24, uint64_t *adj, uint64_t *slots) {
+    const int E = n * (n - 1) / 2, PW = (E + 63) / 64;
+    for (uint64_t t = 0;; ++t) {
+        for (int v = 0; v < n; ++v) adj[v] = 0;
+        int e = 0;
+        for (int v = 1; v < n; ++v)
+            for (int u = 0; u < v; ++u, ++e)
+                if ((uint32_t)(key4(seed, domain, agent, 4096ull + t * (uint64_t)E + (uint64_t)e) >> 40) < p24) {
+                    adj[v] |= 1ull << u;
+                    adj[u] |= 1ull << v;
+                }
+        if (dense_is_connected(adj, n)) break;
+    }
+    gen_permitted_of(seed, domain, agent, E, PW, k, slots, 0);
+}
+void orc_gen_dense_roots(uint64_t seed, uint64_t epoch, uint64_t first_agent, int count, int n, int kmin, int kmax, uint32_t p24,
+                         uint64_t *adj, uint64_t *slots) {
+    const int E = n * (n - 1) / 2, KW = (2 * E + 63) / 64;
+    uint64_t domain = DOMAIN_ROOT ^ (epoch << 32);
+    for (int i = 0; i < count; ++i) {
+        uint64_t agent = first_agent + (uint64_t)i;
+        int k = kmin + (int)below(key4(seed, domain, agent, 0), (uint32_t)(kmax - kmin + 1));
+        uint64_t *so = slots + (size_t)i * KW;
+        for (int w = 0; w < KW; ++w) so[w] = 0;
+        gen_dense_root(seed, domain, agent, n, k, p24, adj + (size_t)i * n, so);
+    }
+}
+/* the dense-graph primitives, exposed for the golden-vector tests */
+int orc_dense_matching_tutte(const uint64_t *adj, int n) { return dense_matching_tutte(adj, n); }
+int orc_dense_matching_reference(const uint64_t *adj, int n) { return dense_matching_reference(adj, n); }
+int orc_dense_is_cut_edge(const uint64_t *adj, int v, int u) { return dense_is_cut_edge(adj, v, u) ? 1 : 0; }
+double orc_dense_lambda1(const uint64_t *adj, int n) { return dense_lambda1(adj, n); }
 void orc_gen_roots(uint64_t seed, uint64_t epoch, uint64_t first_agent, int count, int n, int kmin, int kmax,
                    uint8_t *parents, uint64_t *permitted) {
     int KW = key_words(n);
@@ -986,6 +1079,21 @@ orc_engine *orc_create(int n, int batch, int threads) {
     e->space.S = state_dim(n);
     e->space.KW = key_words(n);
     e->space.root_bytes = n;
+    engine_init(e, batch, threads);
+    return e;
+}
+/* NablaOptimizer over the build-defined dense-graph space (dense_graph.inc) */
+orc_engine *orc_create_dense(int n, int batch, int threads) {
+    if (n < 4 || n > 64) return nullptr;
+    orc_engine *e = new orc_engine();
+    Space &sp = e->space;
+    sp.kind = SPACE_DENSE;
+    sp.n = n;
+    sp.E = n * (n - 1) / 2;
+    sp.A = 2 * sp.E;     /* AddOrDeleteEdge, action.rs:10-27 */
+    sp.S = 3 * sp.E + 1; /* E + ACTION + 1, 05-ah.rs:39-40 */
+    sp.KW = (sp.A + 63) / 64;
+    sp.root_bytes = 8 * n;
     engine_init(e, batch, threads);
     return e;
 }
@@ -1201,7 +1309,7 @@ void orc_argmin(orc_engine *e, uint8_t *parents, uint64_t *permitted, double *la
                 float *eval) {
     pack_state(e->space, e->argmin_state, parents, permitted);
     *lambda1 = e->argmin_cost.lambda1;
-    *matching_size = (int)e->argmin_cost.matching.size();
+    *matching_size = e->space.kind == SPACE_DENSE ? e->argmin_cost.mu : (int)e->argmin_cost.matching.size();
     *eval = e->argmin_eval;
 }
 
@@ -1286,7 +1394,7 @@ void orc_agent_state(orc_engine *e, int agent, uint8_t *parents, uint64_t *permi
     for (uint32_t a : e->paths[agent]) path[a >> 6] |= 1ull << (a & 63);
     *state_pos = e->last_positions[agent];
     *lambda1 = e->costs[agent].lambda1;
-    *matching_size = (int)e->costs[agent].matching.size();
+    *matching_size = e->space.kind == SPACE_DENSE ? e->costs[agent].mu : (int)e->costs[agent].matching.size();
 }
 
 } // extern "C"

@@ -135,6 +135,14 @@ void orc_agent_state(orc_engine *e, int agent, uint8_t *parents, uint64_t *permi
 
 /* ---- evaluator = ActionModel (model/dfdx.rs) as a plain fp32 MLP + Adam ---- */
 /* dims[n_layers+1]; hidden activations ReLU; final_act: 0 none, 1 ReLU, 2 Sigmoid */
+/* ---- the build-defined dense-graph space (oracle/dense_graph.inc; BASELINE configs[4]) */
+orc_engine *orc_create_dense(int n, int batch, int threads);
+void orc_gen_dense_roots(uint64_t seed, uint64_t epoch, uint64_t first_agent, int count, int n, int kmin, int kmax,
+                         uint32_t p24, uint64_t *adj, uint64_t *slots);
+int orc_dense_matching_tutte(const uint64_t *adj, int n);     /* rank(Tutte over GF(2^31 - 1)) / 2 */
+int orc_dense_matching_reference(const uint64_t *adj, int n); /* connected_bitset_graph/mod.rs:235-317, literally */
+int orc_dense_is_cut_edge(const uint64_t *adj, int v, int u); /* :47-71 */
+double orc_dense_lambda1(const uint64_t *adj, int n);
 orc_mlp *orc_mlp_create(int n_layers, const int *dims, int final_act, float lr, float beta1,
                         float beta2, float eps, float l2, uint64_t seed, int threads);
 void orc_mlp_destroy(orc_mlp *m);

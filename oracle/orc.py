@@ -83,6 +83,12 @@ def lib():
         sig("orc_engine_" + name, C.c_int, vp)
     sig("orc_ramsey_counts_new", None, C.c_int, C.c_int, vp, vp, vp, vp)
     sig("orc_ramsey_act_sequence", None, C.c_int, C.c_int, vp, vp, vp, C.c_int, vp, vp)
+    sig("orc_create_dense", vp, C.c_int, C.c_int, C.c_int)
+    sig("orc_gen_dense_roots", None, C.c_uint64, C.c_uint64, C.c_uint64, C.c_int, C.c_int, C.c_int, C.c_int, C.c_uint32, vp, vp)
+    sig("orc_dense_matching_tutte", C.c_int, vp, C.c_int)
+    sig("orc_dense_matching_reference", C.c_int, vp, C.c_int)
+    sig("orc_dense_is_cut_edge", C.c_int, vp, C.c_int, C.c_int)
+    sig("orc_dense_lambda1", C.c_double, vp, C.c_int)
     sig("orc_mlp_create", vp, C.c_int, vp, C.c_int, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float,
         C.c_uint64, C.c_int)
     sig("orc_mlp_destroy", None, vp)
@@ -116,6 +122,45 @@ def gen_ramsey_roots(seed, epoch, first_agent, count, n, n_colors, kmin, kmax):
     permitted = np.zeros((count, kw), np.uint64)
     lib().orc_gen_ramsey_roots(seed, epoch, first_agent, count, n, n_colors, kmin, kmax, _p(colors), _p(permitted))
     return colors, permitted
+
+
+def gen_dense_roots(seed, epoch, first_agent, count, n, kmin, kmax, p=0.2):
+    """seeded roots of the dense-graph space: (adj u64 [count, n], modifiable slots u64 [count, KW])"""
+    e = n * (n - 1) // 2
+    kw = (2 * e + 63) // 64
+    adj = np.zeros((count, n), np.uint64)
+    slots = np.zeros((count, kw), np.uint64)
+    lib().orc_gen_dense_roots(seed, epoch, first_agent, count, n, kmin, kmax, int(round(p * (1 << 24))), _p(adj), _p(slots))
+    return adj, slots
+
+
+def adjacency(n, edges):
+    """neighbourhood bitsets (u64 per vertex) of an edge list"""
+    adj = np.zeros(n, np.uint64)
+    for u, v in edges:
+        adj[u] |= np.uint64(1) << np.uint64(v)
+        adj[v] |= np.uint64(1) << np.uint64(u)
+    return adj
+
+
+def dense_matching_tutte(adj):
+    adj = np.ascontiguousarray(adj, np.uint64)
+    return lib().orc_dense_matching_tutte(_p(adj), len(adj))
+
+
+def dense_matching_reference(adj):
+    adj = np.ascontiguousarray(adj, np.uint64)
+    return lib().orc_dense_matching_reference(_p(adj), len(adj))
+
+
+def dense_is_cut_edge(adj, v, u):
+    adj = np.ascontiguousarray(adj, np.uint64)
+    return bool(lib().orc_dense_is_cut_edge(_p(adj), v, u))
+
+
+def dense_lambda1(adj):
+    adj = np.ascontiguousarray(adj, np.uint64)
+    return lib().orc_dense_lambda1(_p(adj), len(adj))
 
 
 def ramsey_counts_new(n, sizes, colors):
@@ -173,12 +218,14 @@ class Tree:
 class Engine:
     """NablaOptimizer-shaped driver of the oracle with an injectable model."""
 
-    def __init__(self, n, batch, threads=1, ramsey=None, path_kind=0, layers=1):
+    def __init__(self, n, batch, threads=1, ramsey=None, path_kind=0, layers=1, dense=False):
         """ramsey = (sizes, weights) selects RamseySpaceNoEdgeRecolor<B32, n, E, C>; default the c21 space.
         path_kind: 0 ActionSet / ActionMultiset, 1 ActionSequence / OrderedActionSet"""
         self.L = lib()
         self.n, self.B = n, batch
-        if ramsey is None:
+        if dense:
+            self.h = self.L.orc_create_dense(n, batch, threads)
+        elif ramsey is None:
             self.h = self.L.orc_create(n, batch, threads)
         else:
             sizes = np.ascontiguousarray(ramsey[0], np.int32)

@@ -1,0 +1,124 @@
+"""GPU parity tests of the dense-graph space (BASELINE configs[4]; space_dense.inc against oracle/dense_graph.inc): trees
+(keys as action-id sets), state vectors, costs (lambda_1 as f64 bits, matching numbers), counters, observations and
+argmin, bit for bit; N = 50 with the 512-wide bf16 model on the launch-per-phase form with the batched MFMA GEMM."""
+import numpy as np
+import pytest
+
+from test_gpu_parity import MAIN_CTRS, assert_tree_equal
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def az():
+    import azdopt_amd
+    assert azdopt_amd.device_count() > 0, "no MI355X visible"
+    return azdopt_amd
+
+
+def compare(opt, oe, agents, tag):
+    assert np.array_equal(opt.state_vecs(), oe.state_vecs()), tag
+    for i in agents:
+        assert_tree_equal(opt.get_tree(i), oe.export_tree(i), f"{tag} agent {i}")
+        sg, so = opt.agent_state(i), oe.agent_state(i)
+        for k in so:
+            assert np.array_equal(sg[k], so[k]), (tag, i, k, sg[k], so[k])  # lambda_1 compared as an f64: bit-identical procedure
+    cg, co = opt.counters(), oe.counters()
+    for k in MAIN_CTRS:
+        assert cg[k] == co[k], (tag, k, cg[k], co[k])
+    ag, ao = opt.argmin_data(), oe.argmin()
+    assert ag.eval == ao["eval"] and ag.cost["lambda_1"] == ao["lambda1"] and len(ag.cost["matching"]) == ao["matching"], tag
+    assert np.array_equal(ag.state["adj"].view(np.uint8), ao["parents"]) and np.array_equal(ag.state["permitted"], ao["permitted"]), tag
+
+
+def run_dense_parity(az, orc, n, B, p, kmin, kmax, tol, steps, epochs, seed, check_every):
+    space = az.DenseGraphSpace(n, p)
+    model = az.HashStreamModel(space.STATE_DIM, space.ACTION_DIM, seed)
+    roots = space.generate_roots(seed, B, kmin=kmin, kmax=kmax)
+    opt = az.NablaOptimizer.par_new(space, roots, model, B)
+    oe = orc.Engine(n, B, threads=8, dense=True)
+    oe.new_begin(*roots)
+    call = 0
+    oe.new_end(orc.hash_predictions(seed, 0, B, space.ACTION_DIM, call))
+    compare(opt, oe, range(B), "par_new")
+    for epoch in range(epochs):
+        s = 0
+        while s < steps:
+            k = min(check_every, steps - s)
+            ig = opt.par_roll_out_episodes(tol, n_calls=k)
+            io = 0
+            for _ in range(k):
+                oe.rollout_begin(*tol)
+                call += 1
+                io += oe.rollout_end(orc.hash_predictions(seed, 0, B, space.ACTION_DIM, call))
+            assert ig == io
+            s += k
+            compare(opt, oe, range(B), f"epoch {epoch} step {s}")
+        assert opt.step_form()[0] == "per_call" and "dense-graph space" in opt.step_form()[1]
+        sv, obs, w = opt.observe(2)
+        oo, ow = oe.observe(2)
+        assert np.array_equal(obs.view(np.uint32), oo.view(np.uint32)) and np.array_equal(w, ow) and np.array_equal(sv, oe.state_vecs())
+        roots = space.generate_roots(seed, B, epoch=epoch + 1, kmin=kmin, kmax=kmax)  # `modify_root`: fresh seeded roots from the host
+        opt.par_reset_trees(roots)
+        oe.reset_begin(*roots)
+        call += 1
+        oe.reset_end(orc.hash_predictions(seed, 0, B, space.ACTION_DIM, call))
+        compare(opt, oe, range(B), f"epoch {epoch} reset")
+    return opt.counters()
+
+
+def test_dense_parity_small_every_step(az, orc):
+    c = run_dense_parity(az, orc, 8, 12, 0.4, 2, 10, ([6, 3], 2), steps=40, epochs=2, seed=5, check_every=1)
+    assert c["TRANSPOSITIONS"] > 0 and c["TERMINALS"] > 0
+
+
+def test_dense_parity_n20(az, orc):
+    c = run_dense_parity(az, orc, 20, 24, 0.2, 5, 60, ([50, 20, 10], 5), steps=120, epochs=2, seed=2, check_every=30)
+    assert c["EXPANSIONS"] > 1000 and c["TRANSPOSITIONS"] > 0
+
+
+def test_dense_parity_n50_reference_tolerances(az, orc):
+    """BASELINE configs[4]'s N = 50 (E = 1225, ACTION 2450, STATE 3676) with up to 128 modifiable slots per root"""
+    c = run_dense_parity(az, orc, 50, 32, 0.1, 5, 128, ([200, 50, 50], 25), steps=100, epochs=1, seed=1, check_every=50)
+    assert c["EXPANSIONS"] > 2000 and c["MAX_DEPTH"] >= 3
+
+
+def test_dense_roots_are_validated(az):
+    space = az.DenseGraphSpace(12, 0.3)
+    model = az.TrivialModel(space.STATE_DIM, space.ACTION_DIM)
+    adj, slots = space.generate_roots(0, 4)
+    bad = adj.copy().view(np.uint64).reshape(4, 12)
+    bad[1, 3] ^= np.uint64(1 << 7)  # not symmetric any more
+    with pytest.raises(az.AzdError):
+        az.NablaOptimizer.par_new(space, (bad.view(np.uint8).reshape(4, -1), slots), model, 4)
+    lone = np.zeros((4, 12), np.uint64)  # not connected
+    with pytest.raises(az.AzdError):
+        az.NablaOptimizer.par_new(space, (lone.view(np.uint8).reshape(4, -1), slots), model, 4)
+    opt = az.NablaOptimizer.par_new(space, (adj, slots), model, 4)
+    with pytest.raises(az.AzdError):  # the device root policy is not built for this space
+        opt.par_reset_trees_policy(0, 0)
+
+
+def test_dense_n50_with_the_512_wide_bf16_model(az, orc):
+    """config E's model: 3676 -> 512 -> 512 -> 512 -> 2450 with bf16 storage on the batched MFMA GEMM
+    (v_mfma_f32_32x32x16_bf16), one launch per phase; the oracle is fed the GPU's prediction rows and must grow the
+    same trees; then one optimiser step on the f32 master weights"""
+    n, B, seed = 50, 48, 3
+    tol = ([200, 50, 50], 25)
+    space = az.DenseGraphSpace(n, 0.1)
+    model = az.ActionModel(B, space.STATE_DIM, space.ACTION_DIM, hidden=(512, 512, 512), seed=seed, dtype="bf16")
+    roots = space.generate_roots(seed, B)
+    opt = az.NablaOptimizer.par_new(space, roots, model, B)
+    oe = orc.Engine(n, B, threads=8, dense=True)
+    oe.new_begin(*roots)
+    oe.new_end(opt.predictions())
+    for s in range(40):
+        opt.par_roll_out_episodes(tol)
+        oe.rollout_begin(*tol)
+        assert np.array_equal(opt.state_vecs(), oe.state_vecs())
+        oe.rollout_end(opt.predictions())
+    assert opt.step_form()[0] == "per_call"
+    for i in range(B):
+        assert_tree_equal(opt.get_tree(i), oe.export_tree(i), f"agent {i}")
+    loss = opt.par_update_model(2)
+    assert np.isfinite(loss) and loss >= 0

@@ -1,0 +1,125 @@
+"""The oracle's dense-graph space (oracle/dense_graph.inc; BASELINE configs[4]) against the reference's own test vectors
+for general graphs, against brute force, and its space axioms.  CPU only."""
+import itertools
+import json
+import os
+
+import numpy as np
+import pytest
+
+GOLD = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "reference_graph_vectors.json")))
+
+
+def cut_edges(orc, adj):
+    n = len(adj)
+    return sorted((u, v) for v in range(n) for u in range(v) if (int(adj[v]) >> u) & 1 and orc.dense_is_cut_edge(adj, v, u))
+
+
+@pytest.mark.parametrize("case", GOLD["matching"], ids=lambda c: c["name"])
+def test_matching_numbers_of_the_reference_tests(orc, case):
+    adj = orc.adjacency(case["n"], case["edges"])
+    assert orc.dense_matching_reference(adj) == case["matching_number"]  # the literal branch and bound
+    assert orc.dense_matching_tutte(adj) == case["matching_number"]      # what the search uses
+
+
+@pytest.mark.parametrize("case", GOLD["cut_edges"], ids=lambda c: c["name"])
+def test_cut_edges_of_the_reference_tests_under_every_relabeling(orc, case):
+    n = case["n"]
+    perms = itertools.permutations(range(n)) if n <= 4 else [tuple(range(n)), (4, 3, 2, 1, 0), (1, 0, 3, 2, 4)]
+    for sigma in perms:  # block.rs:233-264 runs all of S_4
+        adj = orc.adjacency(n, [(sigma[u], sigma[v]) for u, v in case["edges"]])
+        want = sorted(tuple(sorted((sigma[u], sigma[v]))) for u, v in case["cut_edges"])
+        assert cut_edges(orc, adj) == want, sigma
+
+
+def random_connected(rng, n, p):
+    import scipy.sparse.csgraph as cg
+    while True:
+        edges = [(u, v) for v in range(n) for u in range(v) if rng.random() < p]
+        a = np.zeros((n, n))
+        for u, v in edges:
+            a[u, v] = a[v, u] = 1
+        if edges and cg.connected_components(a)[0] == 1:
+            return edges, a
+
+
+def test_tutte_rank_equals_branch_and_bound_and_cut_edges_equal_the_definition(orc):
+    rng = np.random.default_rng(0)
+    import scipy.sparse.csgraph as cg
+    for trial in range(200):
+        n = int(rng.integers(4, 15))
+        edges, a = random_connected(rng, n, rng.random() * 0.5 + 0.1)
+        adj = orc.adjacency(n, edges)
+        assert orc.dense_matching_tutte(adj) == orc.dense_matching_reference(adj), trial
+        want = []
+        for u, v in edges:  # a cut edge is one whose removal disconnects the graph
+            b = a.copy()
+            b[u, v] = b[v, u] = 0
+            if cg.connected_components(b)[0] > 1:
+                want.append((u, v))
+        assert cut_edges(orc, adj) == sorted(want), trial
+
+
+def test_lambda1_brackets_the_adjacency_spectral_radius(orc):
+    """the power iteration with Collatz-Wielandt bounds stops at a bracket of 1e-7: within that of LAPACK on graphs with a
+    spectral gap; on a long path (ratio of the two largest eigenvalues of A + I ~ 0.996) it runs into its iteration cap
+    and is still within 1e-3"""
+    rng = np.random.default_rng(1)
+    worst = 0.0
+    for trial in range(100):
+        n = int(rng.integers(4, 51))
+        edges, a = random_connected(rng, n, rng.random() * 0.4 + 0.1)
+        worst = max(worst, abs(orc.dense_lambda1(orc.adjacency(n, edges)) - np.linalg.eigvalsh(a)[-1]))
+    assert worst < 2e-7, worst
+    n = 50
+    path = [(i, i + 1) for i in range(n - 1)]
+    a = np.zeros((n, n))
+    for u, v in path:
+        a[u, v] = a[v, u] = 1
+    assert abs(orc.dense_lambda1(orc.adjacency(n, path)) - np.linalg.eigvalsh(a)[-1]) < 1e-3
+    star = [(0, i) for i in range(1, n)]
+    assert abs(orc.dense_lambda1(orc.adjacency(n, star)) - np.sqrt(n - 1)) < 1e-6  # bipartite: A alone would oscillate
+
+
+def test_space_dimensions_roots_and_search(orc):
+    n, B = 10, 5
+    e = orc.Engine(n, B, threads=2, dense=True)
+    E = n * (n - 1) // 2
+    assert (e.S, e.A, e.KW, e.RB) == (3 * E + 1, 2 * E, (2 * E + 63) // 64, 8 * n)  # 05-ah.rs:39-40; action.rs:10-27
+    adj, slots = orc.gen_dense_roots(4, 0, 0, B, n, 3, 12, 0.35)
+    e.new_begin(adj.view(np.uint8).reshape(B, -1), slots)
+    sv = e.state_vecs()
+    for i in range(B):
+        k = sum(bin(int(w)).count("1") for w in slots[i])
+        assert 3 <= k <= 12 and sv[i, 3 * E] == np.float32(k) / np.float32(E)
+        bools = [(int(adj[i, v]) >> u) & 1 for v in range(n) for u in range(v)]
+        assert sv[i, :E].tolist() == bools                      # edge_bools, mod.rs:127-137
+        assert sv[i, E:3 * E].sum() == k                        # every modifiable slot is either addable or deletable
+    e.new_end(orc.hash_predictions(4, 0, B, e.A, 0))
+    for call in range(1, 150):
+        e.rollout_begin([20, 5, 5], 3)
+        e.rollout_end(orc.hash_predictions(4, 0, B, e.A, call))
+    c = e.counters()
+    assert c["EXPANSIONS"] > 100 and c["TRANSPOSITIONS"] > 0 and c["FAILED"] == 0
+    # ActionsNeverRepeat + ActionOrderIndependent: the state of a node is its root plus its SET of actions, in any order
+    t = e.export_tree(0)
+    root = adj[0].copy()
+    for node in range(1, min(len(t.c), 40)):
+        acts = [a for a in range(e.A) if (int(t.keys[node, a >> 6]) >> (a & 63)) & 1]
+        assert len({a % E for a in acts}) == len(acts)          # a slot at most once
+        g = root.copy()
+        for a in acts[::-1]:
+            slot = a % E
+            v = 1
+            while v * (v + 1) // 2 <= slot:
+                v += 1
+            u = slot - v * (v - 1) // 2
+            assert ((int(g[v]) >> u) & 1) == (1 if a >= E else 0)  # Delete removes a present edge, Add adds an absent one
+            g[v] ^= np.uint64(1 << u)
+            g[u] ^= np.uint64(1 << v)
+        lam = orc.dense_lambda1(g)
+        mu = orc.dense_matching_tutte(g)
+        assert mu == orc.dense_matching_reference(g)
+        # evaluate = squish(mu + lambda_1): slope 1 / (ceil(sqrt(N - 1)) + (N + 1) / 2 - 2) (04-c21-tree.rs:58-74)
+        want = np.float32(1.0 / (3 + 5 - 2)) * ((np.float32(mu) + np.float32(lam)) - np.float32(2))
+        assert t.c[node] == want
