@@ -135,6 +135,11 @@ struct azd_engine {
     unsigned long long *d_log_key = nullptr;
     uint32_t *d_log_node = nullptr;
     int log_calls = 0;
+    // launch-per-phase form: the five launches of a call captured once in a hipGraph and replayed per call
+    hipGraphExec_t call_graph = nullptr;
+    azd::TolTable call_graph_tol{};
+    uint64_t call_graph_layout = 0;
+    bool graph_enabled = true;
     // dense-graph space: host-visible key width (action-id sets) and the packed roots as the device wants them
     int kw_host = 0;
     std::vector<uint64_t> dense_packed;
@@ -654,6 +659,7 @@ int azd_engine_create(azd_engine **out, const azd_engine_config *cfg, azd_evalua
     // default: the pool step for populations of 256 agents and more (below that a row's trip to an evaluator CU and
     // back costs more than the asynchronous step's in-workgroup evaluator: 0.36 against 0.49 M expansions/s at 64 agents,
     // 4.7 against 3.7 at 512); AZD_ENGINE_POOL_STEP / AZD_ENGINE_ASYNC_STEP / AZD_ENGINE_BARRIER_STEP force a form
+    e->graph_enabled = getenv("AZD_NO_CALL_GRAPH") == nullptr;
     e->pool_step = (cfg->flags & AZD_ENGINE_POOL_STEP) != 0 ||
                    ((cfg->flags & (AZD_ENGINE_ASYNC_STEP | AZD_ENGINE_BARRIER_STEP)) == 0 && cfg->batch >= 256);
     if (const char *env = getenv("AZD_STEP_FORM")) { // experiments: override the configured form
@@ -725,6 +731,7 @@ int azd_engine_destroy(azd_engine *e) {
     if (e->h_argmin) (void)hipHostFree(e->h_argmin);
     if (e->h_pargs) (void)hipHostFree(e->h_pargs);
     if (e->d_pool) (void)hipFree(e->d_pool);
+    if (e->call_graph) (void)hipGraphExecDestroy(e->call_graph);
     for (auto &it : e->ev_inflight) {
         (void)hipEventDestroy(it.second.first);
         (void)hipEventDestroy(it.second.second);
@@ -897,15 +904,49 @@ int azd_engine_par_roll_out_episodes(azd_engine *e, const uint32_t *tol, int n_t
         }
         AZD_HIP(hipGetLastError());
     } else {
-        for (int c = 0; c < n_calls; ++c) {
-            e->time_begin(0);
-            azd::launch_rollout(e->a, t, e->stream);
-            e->time_end();
-            st = run_evaluator(e); // :175-176
-            if (st) return st;
-            azd::launch_add_actions(e->a, 0, e->stream);
-            azd::launch_argmin(e->a, 0, e->stream); // :190
-        }
+        // One call = roll-out, model call, add_actions, argmin: four to eight launches.  With the MLP evaluator (whose
+        // launches take no per-call arguments) the sequence is captured once into a hipGraph and replayed per call, so
+        // a call costs one graph launch instead of a launch per phase (BASELINE configs[4]: "hipGraph-captured episode
+        // step").  Not while per-launch timing is on (the events would be captured too), nor for evaluators whose
+        // kernels take the call index.
+        const bool graphable = e->graph_enabled && !e->timing && n_calls >= 2 && e->ev->replayable(e->a.B);
+        if (graphable) {
+            if (!e->call_graph || memcmp(&e->call_graph_tol, &t, sizeof(t)) != 0 || e->call_graph_layout != e->ev->layout_version) {
+                if (e->call_graph) (void)hipGraphExecDestroy(e->call_graph);
+                e->call_graph = nullptr;
+                hipGraph_t g = nullptr;
+                AZD_HIP(hipStreamBeginCapture(e->stream, hipStreamCaptureModeThreadLocal));
+                azd::launch_rollout(e->a, t, e->stream);
+                const uint64_t calls_before = e->ev->calls;
+                st = e->ev->write_predictions_dev(e->a.B, e->a.state_vecs, e->a.h_theta, e->stream);
+                e->ev->calls = calls_before;
+                azd::launch_add_actions(e->a, 0, e->stream);
+                azd::launch_argmin(e->a, 0, e->stream);
+                hipError_t he = hipStreamEndCapture(e->stream, &g);
+                if (st) {
+                    if (g) (void)hipGraphDestroy(g);
+                    return st;
+                }
+                if (he != hipSuccess) return azd::hip_fail(he, "hipStreamEndCapture");
+                he = hipGraphInstantiate(&e->call_graph, g, nullptr, nullptr, 0);
+                (void)hipGraphDestroy(g);
+                if (he != hipSuccess) return azd::hip_fail(he, "hipGraphInstantiate");
+                e->call_graph_tol = t;
+                e->call_graph_layout = e->ev->layout_version;
+            }
+            for (int c = 0; c < n_calls; ++c) AZD_HIP(hipGraphLaunch(e->call_graph, e->stream));
+            e->ev->calls += (uint64_t)n_calls;
+            e->step_form = AZD_STEP_PER_CALL_GRAPH;
+        } else
+            for (int c = 0; c < n_calls; ++c) {
+                e->time_begin(0);
+                azd::launch_rollout(e->a, t, e->stream);
+                e->time_end();
+                st = run_evaluator(e); // :175-176
+                if (st) return st;
+                azd::launch_add_actions(e->a, 0, e->stream);
+                azd::launch_argmin(e->a, 0, e->stream); // :190
+            }
     }
     st = sync_status(e);
     if (improved) *improved = (int)(e->h_status->improved - e->seen_improved);

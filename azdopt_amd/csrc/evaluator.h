@@ -26,6 +26,7 @@ struct azd_evaluator {
     int state_dim = 0;
     int action_dim = 0;
     uint64_t calls = 0;
+    uint64_t layout_version = 0; // bumped whenever buffers are reallocated or the storage type changes: a captured graph of write_predictions_dev is stale then
     // staging for the host-pointer entry points
     float *d_states = nullptr, *d_preds = nullptr, *d_obs = nullptr, *d_w = nullptr;
     int staged_batch = 0;
@@ -39,6 +40,9 @@ struct azd_evaluator {
                                  hipStream_t st) = 0;
     // description for the persistent step (evaluator inside the kernel); false = not fusable
     virtual bool fused_desc(azd::FusedEval *) { return false; }
+    // write_predictions_dev(batch) launches the same kernels with the same arguments on every call and allocates nothing
+    // once a batch of that size has run: the engine may capture it into a hipGraph and replay it
+    virtual bool replayable(int /*batch*/) { return false; }
     virtual int64_t num_params() { return 0; }
     virtual int get_params(float *) { return AZD_ERR_UNSUPPORTED; }
     virtual int set_params(const float *) { return AZD_ERR_UNSUPPORTED; }

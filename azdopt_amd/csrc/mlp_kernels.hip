@@ -447,6 +447,7 @@ struct MlpEvaluator : azd_evaluator {
 
     int ensure_batch(int batch) {
         if (batch <= cap_batch) return AZD_OK;
+        layout_version += 1;
         for (float *&p : d_act) {
             if (p) (void)hipFree(p);
             p = nullptr;
@@ -569,6 +570,7 @@ struct MlpEvaluator : azd_evaluator {
         return AZD_OK;
     }
 
+    bool replayable(int batch) override { return batch <= cap_batch; }
     bool fused_desc(FusedEval *f) override {
         memset(f, 0, sizeof(*f));
         if (L > 7) return false;
@@ -614,6 +616,7 @@ struct MlpEvaluator : azd_evaluator {
     int set_weight_storage(int dtype) override {
         AZD_HIP(hipSetDevice(device));
         if (dtype != AZD_STORAGE_F32 && dtype != AZD_STORAGE_BF16) return AZD_ERR_INVALID_ARGUMENT;
+        layout_version += 1;
         AZD_HIP(hipDeviceSynchronize());
         if (dtype == AZD_STORAGE_BF16 && !d_w16) {
             AZD_HIP(hipMalloc(&d_w16, (size_t)n_params * 2));

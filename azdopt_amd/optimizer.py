@@ -287,7 +287,7 @@ class NablaOptimizer:
     def stream(self):
         return self._L.azd_engine_stream(self._h)
 
-    STEP_FORMS = {0: "none", 1: "async", 2: "barrier", 3: "per_call", 4: "pool"}
+    STEP_FORMS = {0: "none", 1: "async", 2: "barrier", 3: "per_call", 4: "pool", 5: "per_call_graph"}
 
     def pool_split(self):
         """(evaluator, searcher) workgroups of the last pool-step launch"""

@@ -50,6 +50,10 @@ WORKLOADS = {
     "r44": dict(kind="ramsey", n=17, sizes=[4, 4], agents=8192, hidden=(256, 256, 256),
                 tol=([200, 200, 100, 100, 50, 50, 25, 25], 10),
                 caps=dict(prediction_capacity=57344), name="Ramsey R(4,4) N=17"),
+    # BASELINE configs[4]: the build-defined dense-graph space (oracle/dense_graph.inc), N = 50, G(50, 0.1) roots with up to
+    # 128 modifiable edge slots, 512-wide model; runs one launch per phase, replayed from a hipGraph
+    "dense50": dict(kind="dense", n=50, p=0.1, agents=8192, hidden=(512, 512, 512), tol=([200, 50, 50], 25),
+                    caps=dict(prediction_capacity=131072), name="dense graphs N=50"),
 }
 # BASELINE.json configs[0..3] as presets: (workload, agents per GPU, evaluator storage)
 CONFIGS = {
@@ -57,11 +61,14 @@ CONFIGS = {
     "B": ("c21", 4096, "f32"),     # configs[1]: the metric's configuration on one GPU
     "C": ("c21", 8192, "bf16"),    # configs[2]: 65536 agents over 8 GPUs, bf16 MLP, RCCL all-gather
     "D": ("r44", 8192, "f32"),     # configs[3]: 32768 agents over 4 GPUs, Ramsey space
+    "E": ("dense50", 8192, "bf16"),  # configs[4]: N = 50 dense graphs, 512-wide bf16 MLP on MFMA, hipGraph-replayed step
 }
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 
 
 def make_space(az, wl):
+    if wl["kind"] == "dense":
+        return az.DenseGraphSpace(wl["n"], wl["p"])
     if wl["kind"] == "ramsey":
         return az.RamseySpaceNoEdgeRecolor(wl["n"], wl["sizes"])
     return az.ROTModifyParentsOnce(wl["n"])
@@ -94,7 +101,11 @@ def _cpu_run(orc, wl, hidden, B, n_threads, krange, max_calls, budget_s, with_ml
     Only the restatement's own work is timed (tree phases, and the MLP forward when with_mlp): generating the
     fixed prediction stream of the tree-only run is not."""
     n, TOL = wl["n"], wl["tol"]
-    if wl["kind"] == "ramsey":
+    if wl["kind"] == "dense":
+        e = orc.Engine(n, B, threads=n_threads, dense=True)
+        adj, permitted = orc.gen_dense_roots(SEED, 0, 0, B, n, *krange, p=wl["p"])
+        parents = adj.view(np.uint8).reshape(B, -1)
+    elif wl["kind"] == "ramsey":
         e = orc.Engine(n, B, threads=n_threads, ramsey=(wl["sizes"], [1.0] * len(wl["sizes"])))
         parents, permitted = orc.gen_ramsey_roots(SEED, 0, 0, B, n, len(wl["sizes"]), *krange)
     else:
@@ -214,7 +225,10 @@ def main():
     def epoch_boundary():
         nonlocal epoch, boundaries
         losses.append(sopt.par_update_model(N_OBS_TOL))  # N > 1: all-gather of the training triple, then the identical step
-        sopt.par_reset_trees_policy(SEED, epoch)         # modify_root policy + reset on the device
+        if wl["kind"] == "dense":  # no device root policy for this space: `modify_root` = fresh seeded roots from the host
+            sopt.par_reset_trees(space.generate_roots(SEED, B, first_agent=sopt.plan.first_agent, epoch=epoch + 1))
+        else:
+            sopt.par_reset_trees_policy(SEED, epoch)     # modify_root policy + reset on the device
         epoch += 1
         boundaries += 1
 
@@ -237,7 +251,11 @@ def main():
         run(lead)
         placed = (calls_done + args.warmup) % EPOCH_CALLS
     run(args.warmup)
-    opt.set_timing(True)
+    # per-launch HIP-event timing: free for the CU-resident forms (one launch per <= 800 calls); the launch-per-phase form
+    # is replayed from a hipGraph only while it is off, so there it is taken on a short run of its own after the timed one
+    form_now = opt.step_form()[0]
+    per_call = form_now.startswith("per_call") or (form_now == "none" and wl["kind"] == "dense")
+    opt.set_timing(not per_call)
     c0 = opt.counters()
     b0 = boundaries
     barrier()
@@ -246,10 +264,18 @@ def main():
     barrier()
     dt = time.perf_counter() - t0
     c1 = opt.counters()
-    timing = opt.timing()
-    opt.set_timing(False)
     n_bound = boundaries - b0
     form, form_why = opt.step_form()
+    timing_note = None
+    if per_call:
+        k = min(20, EPOCH_CALLS - calls_done % EPOCH_CALLS - 1)
+        if k > 0:
+            opt.set_timing(True)
+            sopt.par_roll_out_episodes(TOL, n_calls=k)
+            calls_done += k
+            timing_note = "kernel durations from %d extra calls timed launch by launch after the timed region (which replays a hipGraph)" % k
+    timing = opt.timing()
+    opt.set_timing(False)
     if c1["FAILED"] != 0:
         raise SystemExit("bench: %d agents stopped on a full arena; the rate would count fewer working agents" % c1["FAILED"])
 
@@ -263,17 +289,23 @@ def main():
     else:
         dt_max, exp_total = dt, float(exp_local)
     best_eval, best_cost = sopt.global_argmin()
+    if per_call:  # the roofline figures below describe the extra launch-by-launch calls, not the graph replays
+        exp_for_roofline = opt.counters()["EXPANSIONS"] - c1["EXPANSIONS"]
+    else:
+        exp_for_roofline = c1["EXPANSIONS"] - c0["EXPANSIONS"]
 
     if rank == 0:
-        state_bytes = (space.C * space.E * 4 + 512) if wl["kind"] == "ramsey" else 0
+        state_bytes = (space.C * space.E * 4 + 512) if wl["kind"] == "ramsey" else (1024 if wl["kind"] == "dense" else 0)
         bytes_per_exp, d = algorithmic_bytes(c0, c1, space.STATE_DIM, space.ACTION_DIM, state_bytes)
         kw = space.KEY_WORDS
         dims_txt = "-".join(str(x) for x in (space.STATE_DIM,) + HIDDEN + (space.ACTION_DIM,))
         launches = max(1, timing["rollout_launches"])
         avg_ms = timing["rollout_ms"] / launches
-        bytes_per_launch = bytes_per_exp * exp_local / launches
+        bytes_per_launch = bytes_per_exp * exp_for_roofline / launches
         achieved = bytes_per_launch / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
-        kernel = {"async": "k_async<%d>", "barrier": "k_persist<%d>", "per_call": "k_rollout<%d>", "pool": "k_pool<%d>"}.get(form, "?<%d>") % kw
+        kw = 2 if wl["kind"] == "dense" else kw  # device keys of the dense space: ranks of the root's modifiable slots
+        kernel = {"async": "k_async<%d>", "barrier": "k_persist<%d>", "per_call": "k_rollout<%d>", "per_call_graph": "k_rollout<%d>",
+                  "pool": "k_pool<%d>"}.get(form, "?<%d>") % kw
         # HBM traffic is not measured by this process (PMC counters need rocprofv3): it is the per-call figure of the
         # committed profile of the same kernel and workload, scaled to this run's calls per launch, or null
         traffic, traffic_src = None, None
@@ -314,7 +346,8 @@ def main():
             "calls_per_launch": args.steps / launches,
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src, "kernel": kernel,
-                         "algorithmic_bytes_per_expansion": bytes_per_exp, "avg_launch_ms": avg_ms,
+                         "algorithmic_bytes_per_expansion": bytes_per_exp, "avg_launch_ms": avg_ms, "timing_note": timing_note,
+                         "evaluator_ms_per_call": (timing["evaluator_ms"] / launches) if per_call else None,
                          "mlp_flop_per_launch": 2.0 * sum(a * b for a, b in zip((space.STATE_DIM,) + HIDDEN, HIDDEN + (space.ACTION_DIM,)))
                                                 * ((B + 15) // 16 * 16) * args.steps / launches,
                          "note": "latency-bound pointer chasing: the rate target and the 40% roofline target are "

@@ -393,6 +393,7 @@ void *azd_engine_stream(azd_engine *e); /* hipStream_t the engine launches on */
 #define AZD_STEP_BARRIER 2
 #define AZD_STEP_PER_CALL 3
 #define AZD_STEP_POOL 4
+#define AZD_STEP_PER_CALL_GRAPH 5 /* AZD_STEP_PER_CALL with the launches of a call captured in a hipGraph and replayed */
 int azd_engine_step_form(azd_engine *e, int *form, const char **reason);
 /* how the last pool-step launch split the CUs: evaluator / searcher workgroups */
 int azd_engine_pool_split(azd_engine *e, int *eval_wgs, int *search_wgs);

@@ -122,3 +122,38 @@ def test_dense_n50_with_the_512_wide_bf16_model(az, orc):
         assert_tree_equal(opt.get_tree(i), oe.export_tree(i), f"agent {i}")
     loss = opt.par_update_model(2)
     assert np.isfinite(loss) and loss >= 0
+
+
+def test_hipgraph_replay_of_the_per_call_form_equals_launch_by_launch(az):
+    """with the MLP evaluator the launches of a call (roll-out, GEMMs, add_actions, argmin) are captured once in a
+    hipGraph and replayed per call: same trees, counters, argmin and improvement count as launching them one by one"""
+    n, B, seed = 20, 40, 6
+    tol = ([50, 20, 10], 5)
+    space = az.DenseGraphSpace(n, 0.2)
+    roots = space.generate_roots(seed, B)
+    runs = []
+    for graph in (True, False):
+        model = az.ActionModel(B, space.STATE_DIM, space.ACTION_DIM, hidden=(128, 128), seed=seed, dtype="bf16")
+        o = az.NablaOptimizer.par_new(space, roots, model, B)
+        if graph:
+            imp = o.par_roll_out_episodes(tol, n_calls=60)
+            assert o.step_form()[0] == "per_call_graph"
+            imp += o.par_roll_out_episodes(tol, n_calls=30)  # the cached graph again
+        else:
+            imp = sum(o.par_roll_out_episodes(tol, n_calls=1) for _ in range(90))
+            assert o.step_form()[0] == "per_call"
+        runs.append((o, imp))
+    (o0, i0), (o1, i1) = runs
+    assert i0 == i1
+    c0, c1 = o0.counters(), o1.counters()
+    for k in MAIN_CTRS:
+        assert c0[k] == c1[k], k
+    for i in range(B):
+        assert_tree_equal(o0.get_tree(i), o1.get_tree(i), f"agent {i}")
+    assert o0.argmin_data().eval == o1.argmin_data().eval
+    # c21 on the launch-per-phase form takes the same path
+    sp = az.ROTModifyParentsOnce(19)
+    m = az.ActionModel(64, sp.STATE_DIM, sp.ACTION_DIM, hidden=(256, 256, 256), seed=1)
+    o = az.NablaOptimizer.par_new(sp, sp.generate_roots(1, 64), m, 64, persistent=False)
+    o.par_roll_out_episodes(([200, 50, 50], 25), n_calls=10)
+    assert o.step_form()[0] == "per_call_graph"

@@ -94,7 +94,7 @@ def test_step_form_reports_the_fallback_and_its_reason(az):
     assert o.step_form()[0] == "none"
     o.par_roll_out_episodes(TOL_REF, n_calls=2)
     form, why = o.step_form()
-    assert form == "per_call" and "multiple of 4" in why
+    assert form == "per_call_graph" and "multiple of 4" in why  # one launch per phase, replayed from a hipGraph
     o2 = az.NablaOptimizer.par_new(space, roots, model, B, persistent=False)
     o2.par_roll_out_episodes(TOL_REF, n_calls=1)
     assert o2.step_form() == ("per_call", "AZD_ENGINE_NO_PERSISTENT_STEP")
