@@ -310,16 +310,26 @@ def main():
         # committed profile of the same kernel and workload, scaled to this run's calls per launch, or null
         traffic, traffic_src = None, None
         tpath = os.path.join(ROOT, "profiles", "traffic.json")
-        if os.path.exists(tpath) and wl_name == "c21" and AGENTS_PER_GPU == 4096 and mlp_dtype == "f32" and form in ("async", "barrier"):
+        if os.path.exists(tpath) and wl_name == "c21" and AGENTS_PER_GPU == 4096 and mlp_dtype == "f32" and form in ("async", "pool"):
             try:
                 tj = json.load(open(tpath))
-                per_call = tj.get("k_async_hbm_bytes_per_call" if form == "async" else "k_persist_hbm_bytes_per_call")
-                if per_call:
-                    traffic = per_call * args.steps / launches
-                    traffic_src = "profiles/traffic.json (rocprofv3 --pmc TCC counters of %s, 800-call launches: %s) x %.0f calls per launch; not measured in this run" \
-                                  % (kernel, tj.get("source", "see profiles/README.md"), args.steps / launches)
+                # FETCH_SIZE as counted (one 64-B request per missed record: profiles/r02_gather_calib.txt) + WRITE_SIZE
+                per_call = tj["k_pool_hbm_bytes_per_call"] if form == "pool" else tj["k_async"]["hbm_bytes_per_call_raw"]
+                traffic = per_call * args.steps / launches
+                traffic_src = "profiles/traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE of %s in separate passes over 800-call launches, " \
+                              "calibrated for record gathers by profiles/r02_gather_calib.txt) x %.0f calls per launch; not measured in this run" \
+                              % (kernel, args.steps / launches)
             except Exception:
                 traffic = None
+        # the limiter the kernel actually runs into: a call is a CHAIN of dependent gathers (a node's predictions, then its
+        # children's records, per selection step; table probes; cascade records), one round trip each for the wave that runs
+        # it.  Bound: resident searching waves / (dependent round trips per call x the idle HBM-miss latency of
+        # MI355X_MICROARCH.md, ~900 cycles = 375 ns).  What separates `achieved` from it: queueing behind the other waves'
+        # misses on the CU's in-order memory path, and the arithmetic between the loads (lambda_1).
+        chain = (2 * d["SELECT_CALLS"] + 2 * (d["EXPANSIONS"] + d["TERMINALS"] + d["TRANSPOSITIONS"]) + d["CASCADE_NODES"]) / max(1, d["EXPANSIONS"]) + 8
+        waves = opt.pool_split()[1] * 16 if form == "pool" else min(B, 4096)
+        lat_peak = waves / (chain * 0.375e-6)
+        lat_rate = exp_for_roofline / launches / (avg_ms * 1e-3) if avg_ms > 0 else 0.0
         if n_bound:
             window = "%d calls incl. %d epoch boundar%s (par_update_model + root policy + par_reset_trees; %d calls/epoch)" \
                      % (args.steps, n_bound, "y" if n_bound == 1 else "ies", EPOCH_CALLS)
@@ -351,7 +361,11 @@ def main():
                          "mlp_flop_per_launch": 2.0 * sum(a * b for a, b in zip((space.STATE_DIM,) + HIDDEN, HIDDEN + (space.ACTION_DIM,)))
                                                 * ((B + 15) // 16 * 16) * args.steps / launches,
                          "note": "latency-bound pointer chasing: the rate target and the 40% roofline target are "
-                                 "~3 orders of magnitude apart for this workload (SURVEY.md 8d)"},
+                                 "~3 orders of magnitude apart for this workload (SURVEY.md 8d); see roofline_latency"},
+            "roofline_latency": {"bound": "hbm-latency", "achieved": lat_rate, "peak": lat_peak, "unit": "expansions/s per GPU",
+                                 "frac": lat_rate / lat_peak if lat_peak else None, "searching_waves": waves,
+                                 "dependent_round_trips_per_call": chain, "miss_latency_ns": 375,
+                                 "note": "peak = searching waves / (dependent gathers per call x idle HBM-miss latency)"},
         }
         if not args.no_cpu_baseline and world == 1:  # timed beside the GPU run at N = 1 only
             out["cpu_baseline"] = cpu_baseline(min(os.cpu_count() or 1, 64), wl, HIDDEN, space.default_permitted_range(), args.cpu_seconds)

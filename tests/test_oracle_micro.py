@@ -132,3 +132,102 @@ def test_hand_worked_scenario_device():
     check(opt.get_tree(0), expected())
     c = opt.counters()
     assert (c["EXPANSIONS"], c["TERMINALS"], c["TRANSPOSITIONS"], c["VISITED_STEPS"], c["ROOT_EXHAUSTED"]) == (3, 2, 2, 1, 1)
+
+
+# ---------------------------------------------------------------- forced two-parent cascades, stepped by hand
+def _diamond(c_r, c_p1, c_p2, c_m, extra_p2=False):
+    """R --a0--> P1 --a2--> M, R --a1--> P2 --a2'--> M: a hand-built diamond (what ActionSet keys give for
+    {a0, a2} = {a1, a2'}), P1 and P2 with M as their only action (P2 with one more unexpanded action if extra_p2)."""
+    t = po.PyTree()
+    h = np.zeros(8, F)
+    r = t.add_node(frozenset(), F(c_r))
+    t.add_actions(r, [0, 1], h)
+    p1 = t.add_node(frozenset({0}), F(c_p1))
+    t.add_edge(r, p1, 0)
+    t.add_actions(p1, [2], h)
+    p2 = t.add_node(frozenset({1}), F(c_p2))
+    t.add_edge(r, p2, 1)
+    t.add_actions(p2, [3, 4] if extra_p2 else [3], h)
+    m = t.add_node(frozenset({0, 2}), F(c_m))
+    t.add_edge(p1, m, t.node[p1]["a0"])
+    t.add_edge(p2, m, t.node[p2]["a0"])  # the transposition arc: M's second in-neighbour
+    t.add_actions(m, [5], h)
+    return t, (r, p1, p2, m)
+
+
+def test_two_parent_cascade_new_terminal_by_hand():
+    """empty_transitions.rs:50-87 through a node with TWO in-neighbours.  M's only action leads to a new terminal T
+    with c_T = 0.25.  By hand: sweep {M: (0.25, 1)}: M exhausted 1, c* 0.5 > 0.25 -> 0.25 (n_t stays 0), now inactive ->
+    (0.25, 1) to both in-neighbours (:75-85).  Level {P1, P2}, smallest index first (:62 pop_first): P1 exhausted 1,
+    c* 0.4 -> 0.25, inactive -> R gets (0.25, 1); P2 exhausted 1, c* 0.2 is NOT improved -> n_t 1 (:66-70), inactive ->
+    R's entry is UPDATED: c = min(0.25, 0.25), n = 1 + 1 (:80-84).  R: exhausted 2, c* 0.3 -> 0.25, inactive; no
+    in-neighbours, the sweep ends."""
+    t, (r, p1, p2, m) = _diamond(0.3, 0.4, 0.2, 0.5)
+    tt = t.add_node(frozenset({0, 2, 5}), F(0.25))
+    e = t.add_edge(m, tt, t.node[m]["a0"])
+    t.cascade(e, old=False)
+    got = [(nd["x"], nd["n"], nd["cs"]) for nd in t.node]
+    assert got == [(2, 0, F(0.25)), (1, 0, F(0.25)), (1, 1, F(0.2)), (1, 0, F(0.25)), (0, 0, F(0.25))]
+    assert [t.active(i) for i in (r, p1, p2, m)] == [False] * 4
+
+
+def test_two_parent_cascade_old_node_by_hand():
+    """empty_transitions.rs:89-127.  M's only action hits an EXISTING inactive node X (c* 0.35, n_t 7): initial info
+    (0.35, 1) (:92-99).  M: exhausted 1, c* 0.5 -> 0.35, then n_t = max(0, 7) = 7 (:110), inactive -> (0.35, 1) to P1, P2.
+    P1: exhausted 1, c* 0.4 -> 0.35, n_t = max(0, 7) = 7, inactive -> R (0.35, 1).  P2 (one more unexpanded action):
+    exhausted 1 of 2, c* 0.2 not improved -> n_t 1, then max(1, 7) = 7; still ACTIVE -> its info carries n = 0, R's
+    entry becomes (0.35, 1 + 0).  R: exhausted 1 of 2, c* 0.3 not improved -> n_t 1 -> max(1, 7) = 7; active."""
+    t, (r, p1, p2, m) = _diamond(0.3, 0.4, 0.2, 0.5, extra_p2=True)
+    x = t.add_node(frozenset({9}), F(0.35))  # an inactive node somewhere else in the tree (no actions = inactive)
+    t.node[x]["n"] = 7
+    e = t.add_edge(m, x, t.node[m]["a0"])
+    t.cascade(e, old=True)
+    got = [(nd["x"], nd["n"], nd["cs"]) for nd in t.node[:4]]
+    assert got == [(1, 7, F(0.3)), (1, 7, F(0.35)), (1, 7, F(0.2)), (1, 7, F(0.35))]
+    assert [t.active(i) for i in (r, p1, p2, m)] == [True, False, True, False]
+
+
+def test_a_sweep_never_meets_an_already_inactive_ancestor():
+    """empty_transitions.rs:69-73 sends `1` for every visited node that is inactive AFTER its update, whether or not it
+    was inactive before.  Re-counting would need a sweep to visit a node that was already inactive -- which cannot
+    happen: a node turns inactive only when all its actions are counted, every counted child being inactive itself, so
+    an inactive node has no active descendant; a sweep starts at the node the agent stands on (active: it has just
+    offered an unvisited action) and visits that node's ancestors only.  Checked here over random searches (the merge of
+    two infos for one ancestor, by contrast, happens all the time)."""
+    hits = dict(visits=0, inactive_before=0, merges=0)
+    orig = po.PyTree.cascade
+
+    def watched(self, e, old):
+        u0, t, _ = self.edge[e]
+        level = {u0}
+        seen_before = {u: self.active(u) for u in range(len(self.node))}
+        while level:  # the ancestors the sweep will visit, level by level
+            nxt = set()
+            for u in level:
+                hits["visits"] += 1
+                hits["inactive_before"] += 0 if seen_before[u] else 1
+                parents = [self.edge[ie][0] for ie in self.inn[u]]
+                hits["merges"] += len(parents) - len(set(parents) - nxt) if parents else 0
+                nxt.update(parents)
+            level = nxt
+        return orig(self, e, old)
+
+    po.PyTree.cascade = watched
+    try:
+        rng = np.random.default_rng(0)
+        for n in (5, 6, 7):
+            _, A = po.dims(n)
+            for _ in range(12):
+                e = po.PyEngine(n, 1)
+                parents = [0] * n
+                for v in range(2, n - 1):
+                    parents[v] = int(rng.integers(0, v))
+                perm = set(int(x) for x in rng.choice(A, int(rng.integers(2, A + 1)), replace=False))
+                e.new_begin([(parents, perm)])
+                e.new_end(rng.random((1, A), dtype=np.float32))
+                for _ in range(120):
+                    e.rollout_begin([3, 2], 1)
+                    e.rollout_end(rng.random((1, A), dtype=np.float32))
+    finally:
+        po.PyTree.cascade = orig
+    assert hits["visits"] > 2000 and hits["merges"] > 100 and hits["inactive_before"] == 0, hits
