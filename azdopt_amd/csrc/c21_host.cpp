@@ -5,6 +5,7 @@
 // shard-invariant -- the stream of an agent depends only on (seed, epoch, global agent id)).
 #include "c21_host.h"
 
+#include <cmath>
 #include <vector>
 
 namespace azd {
@@ -30,6 +31,13 @@ float c21_eval_slope(int n) { // 04-c21-tree.rs:58-74
     int sq = (r * r == n - 1) ? r : r + 1;
     int upper = sq + (n + 1) / 2;
     return 1.0f / (float)(upper - 2);
+}
+
+// initial bracket of the lambda_1 multisection: path (smallest lambda_1 among trees on n vertices, 2 cos(pi / (n + 1)))
+// and star (largest, sqrt(n - 1)), rounded to f32 and widened by 2^-20 -- the same doubles as the oracle's
+void c21_lambda_bracket(int n, double *lo, double *hi) {
+    *lo = (double)(float)(2.0 * std::cos(3.14159265358979323846 / (double)(n + 1))) - 0x1p-20;
+    *hi = (double)(float)std::sqrt((double)(n - 1)) + 0x1p-20;
 }
 
 void c21_shuffle_permitted(uint64_t seed, uint64_t domain, uint64_t agent, int n, int k, uint64_t *permitted) {

@@ -16,6 +16,7 @@ int c21_state_dim(int n);
 int c21_action_dim(int n);
 int c21_key_words(int n);
 float c21_eval_slope(int n);
+void c21_lambda_bracket(int n, double *lo, double *hi);
 
 void c21_shuffle_permitted(uint64_t seed, uint64_t domain, uint64_t agent, int n, int k, uint64_t *permitted);
 void c21_fresh_root(uint64_t seed, uint64_t domain, uint64_t agent, int n, int k, uint8_t *parents,

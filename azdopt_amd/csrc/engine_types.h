@@ -133,6 +133,7 @@ struct Arenas {
     StatusRec *status;
     int n, A, S, KW, B;
     float eval_slope;       // squish slope 1/(C_UPPER - C_LOWER), 04-c21-tree.rs:58-74
+    double lam_lo, lam_hi;  // c21: initial bracket of the lambda_1 multisection (c21_host.cpp:c21_lambda_bracket)
     // ---- Ramsey space (space_ramsey.inc); unused (null / 0) for c21
     int space;              // SPACE_C21 / SPACE_RAMSEY
     int C, E;               // colours, edges N(N-1)/2;  A = E*C, S = E*(2C+1)
@@ -202,8 +203,15 @@ struct PoolCtl {
     uint32_t claim_next, pad0[31];  // next agent no searcher has taken yet in this launch
     uint32_t done_agents, pad1[31]; // agents through all their calls
     uint32_t abort, pad2[31];       // a wait ran into its bound: every loop leaves
-    PoolQ ready[POOL_XCDS];         // agents whose prediction row has arrived, by home XCD
-    PoolQ evalq[POOL_XCDS];         // agents waiting for a prediction row, by home XCD
+    // agents whose prediction row has arrived, by home XCD: ticket queues of agent ids.  Plain mode
+    // (PoolArgs::ready_lanes == 0): everything goes through ready[1].  Lane mode (more agents than searching waves):
+    // ready[0] takes the agents behind the mean progress; a wave looking for work takes a ticket of ready[0] while that
+    // queue holds agents or has fewer than a handful of waves standing by, so a lagging agent never waits for a wave.
+    PoolQ ready[2][POOL_XCDS];
+    PoolQ evalq[2][POOL_XCDS];      // agents waiting for a prediction row, by home XCD; [0] = agents that lag behind, served first
+    struct {
+        uint32_t v, pad[31];
+    } sum_calls[POOL_XCDS], claimed[POOL_XCDS]; // calls completed by / agents living on each XCD: their ratio is the mean progress
 };
 struct PendRec { // what a call that ended on a new node leaves for the add_actions that follows the evaluator
     uint32_t pos;
@@ -213,11 +221,13 @@ struct PendRec { // what a call that ended on a new node leaves for the add_acti
 };
 struct PoolArgs {
     PoolCtl *ctl;
-    uint32_t *ready_slots; // [POOL_XCDS][qcap]  agent + 1, 0 = empty
-    uint32_t *eval_slots;  // [POOL_XCDS][qcap]  (agent + 1) | home XCD << 24
+    uint32_t *ready_slots; // [2][POOL_XCDS][qcap]  agent + 1, 0 = empty
+    uint32_t *eval_slots;  // [2][POOL_XCDS][qcap]  (agent + 1) | home XCD << 24
+    int ready_lanes;       // 1: lane mode
     uint32_t qcap;         // power of two >= 2 * B
     uint32_t *calls_done;  // [B] calls of this launch the agent has completed
     PendRec *pend;         // [B]
+    unsigned long long *stamp; // [B] diagnostic build (make PROFILE=1): when the agent was posted / its row stored
     int n_eval;            // blocks [0, n_eval) are evaluator workgroups
     uint32_t eval_stride;  // floats per row of an evaluator batch in LDS
     uint32_t eval_out_off; // offset (floats) of the head's output inside a row

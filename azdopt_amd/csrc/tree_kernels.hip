@@ -6,6 +6,7 @@
 #include <hip/hip_runtime.h>
 
 #include "bf16.h"
+#include "c21_host.h"
 #include "engine_types.h"
 
 namespace azd {
@@ -149,7 +150,7 @@ __global__ void k_probe_sqrt_alt(const float *in, float *out, int n) {
 
 // lambda_1 / matching probe: one wave per tree, `reps` repetitions (timing), result of the last one
 __global__ __launch_bounds__(64) void k_probe_cost(const uint8_t *__restrict__ parents, int n, int count, int reps,
-                                                   int full, double *__restrict__ lam_out, int *__restrict__ mu_out) {
+                                                   int full, double *__restrict__ lam_out, int *__restrict__ mu_out, double lo0, double hi0) {
     __shared__ WaveLds s;
     const uint32_t dyn = 0;
     const int t = blockIdx.x;
@@ -160,7 +161,7 @@ __global__ __launch_bounds__(64) void k_probe_cost(const uint8_t *__restrict__ p
     int mu = 0;
     for (int r = 0; r < reps; ++r) {
         const PackedTree pt = pack_tree(s, n);
-        lam = full ? lambda1_wave<true>(pt, n, dyn) : lambda1_wave<false>(pt, n, dyn);
+        lam = full ? lambda1_wave<true>(pt, n, dyn, lo0, hi0) : lambda1_wave<false>(pt, n, dyn, lo0, hi0);
         mu = full ? matching_wave(s, n, nullptr) : matching_size_wave(pt, n);
         WAVE_SYNC();
     }
@@ -286,7 +287,9 @@ void launch_hash_predictions(float *d_out, int batch, int action_dim, uint64_t s
 }
 void launch_probe_cost(const uint8_t *d_parents, int n, int count, int reps, int full, double *d_lam, int *d_mu,
                        void *stream) {
-    k_probe_cost<<<dim3(count), dim3(64), dyn_lds_bytes(n), (hipStream_t)stream>>>(d_parents, n, count, reps, full, d_lam, d_mu);
+    double lo0, hi0;
+    c21_lambda_bracket(n, &lo0, &hi0);
+    k_probe_cost<<<dim3(count), dim3(64), dyn_lds_bytes(n), (hipStream_t)stream>>>(d_parents, n, count, reps, full, d_lam, d_mu, lo0, hi0);
 }
 void launch_probe_math(const float *d_in, float *d_out, int n, void *stream) {
     hipLaunchKernelGGL(k_probe_math, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, d_in, d_out, n);

@@ -196,8 +196,17 @@ inline bool posdef_at(const uint8_t *parents, int n, double x) {
  * node_mode: stop as soon as both ends of the bracket round to the same f32 -- the f32 value the
  * evaluation uses (04-c21-tree.rs:100 `*lambda_1 as f32`) is then already the one the full-precision
  * bracket would give, so tree topology cannot depend on the early stop.  Returns hi. */
+/* Initial bracket (round 2; [1, N] before): among the trees on n vertices the path has the smallest lambda_1,
+ * 2 cos(pi / (n + 1)), and the star the largest, sqrt(n - 1); both rounded to f32 and widened by 2^-20, so that every
+ * restatement and the device start from the same doubles whatever their libm's last bit.  Saves most node costs the sixth
+ * round (2.35 / 33^5 is below an f32 ulp, 17 / 33^5 is not). */
+void lambda1_bracket(int n, double *lo, double *hi) {
+    *lo = (double)(float)(2.0 * std::cos(3.14159265358979323846 / (double)(n + 1))) - 0x1p-20;
+    *hi = (double)(float)std::sqrt((double)(n - 1)) + 0x1p-20;
+}
 double lambda1_sturm(const uint8_t *parents, int n, bool node_mode) {
-    double lo = 1.0, hi = (double)n;
+    double lo, hi;
+    lambda1_bracket(n, &lo, &hi);
     for (int round = 0; round < 12; ++round) {
         if (node_mode && (float)lo == (float)hi) break;
         double w = (hi - lo) / 33.0;

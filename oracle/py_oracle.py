@@ -13,6 +13,8 @@ Reference files followed (relative to /root/reference):
   graph-state/src/rooted_tree/{mod,modify_parent_once,ordered_edge,space}.rs, simple_graph/edge.rs
   graph-state/examples/04-c21-tree.rs
 """
+import math
+
 import numpy as np
 
 F = np.float32
@@ -122,7 +124,10 @@ def posdef(parents, n, x):
 def lambda1(parents, n, node_mode=False):
     """cost contract for lambda_1: 33-section of [1, N], <= 12 rounds; node_mode stops as
     soon as both bracket ends round to the same f32 (what the evaluation uses)"""
-    lo, hi = 1.0, float(n)
+    # initial bracket: among the trees on n vertices the path has the smallest lambda_1, 2 cos(pi / (n + 1)), the star the
+    # largest, sqrt(n - 1); both rounded to f32 and widened by 2^-20 (so that every restatement starts from the same doubles)
+    lo = float(F(2.0 * math.cos(math.pi / (n + 1)))) - 2.0 ** -20
+    hi = float(F(math.sqrt(float(n - 1)))) + 2.0 ** -20
     for _ in range(12):
         if node_mode and F(lo) == F(hi):
             break
