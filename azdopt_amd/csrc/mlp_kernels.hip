@@ -170,47 +170,58 @@ __global__ __launch_bounds__(256) void k_gemm(const float *__restrict__ A, int l
 //   global loads are in flight while the current one is multiplied.
 // K and the row pitches must be multiples of 4 (16-byte f32 / 8-byte bf16 vector loads); other shapes take k_gemm.
 typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
-constexpr int GB_M = 128, GB_N = 128, GB_K = 32, GB_LD = 40; // LDS row pitch in bf16 elements (80 B)
-__global__ __launch_bounds__(256, 2) void k_gemm_bf16(const float *__restrict__ X, int ldx, const uint16_t *__restrict__ W, int ldw,
+// MI = 32-row MFMA tiles per wave along M: the block tile is 64 MI x 128.  MI = 2 (128 x 128) reuses each W tile over more
+// rows; MI = 1 (64 x 128) gives twice the blocks -- at the evaluator's shapes (M = 8192, N = 512: 256 blocks of 128 x 128,
+// four waves per CU) the k loop is bound by the latency of its global loads, and more resident waves hide it better than
+// a bigger tile saves traffic (profiles/r02_gemm.txt).
+constexpr int GB_N = 128, GB_K = 32, GB_LD = 40; // LDS row pitch in bf16 elements (80 B)
+template <int MI>
+__global__ __launch_bounds__(256, MI == 1 ? 4 : 2) void k_gemm_bf16(const float *__restrict__ X, int ldx, const uint16_t *__restrict__ W, int ldw,
                                                       float *__restrict__ Y, int ldy, int M, int N, int K, int act, int round_out,
                                                       const float *__restrict__ bias) {
+    constexpr int GB_M = 64 * MI;
     __shared__ __attribute__((aligned(16))) uint16_t sA[GB_M * GB_LD];
     __shared__ __attribute__((aligned(16))) uint16_t sB[GB_N * GB_LD];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
     const int m0 = blockIdx.y * GB_M, n0 = blockIdx.x * GB_N;
-    // staging: thread t moves 16 consecutive k of row t >> 1 (A: four float4, B: four 8-byte groups)
+    // staging: A: thread t moves 8 MI consecutive k of row t / (4 / MI) (2 MI float4); B: 16 consecutive k of row t >> 1
+    constexpr int AQ = 2 * MI;                       // float4 groups per thread
+    const int arow = tid / (4 / MI), akof = (tid % (4 / MI)) * (8 * MI);
     const int srow = tid >> 1, skof = (tid & 1) * 16;
-    const float *xa = X + (size_t)(m0 + srow) * ldx + skof;
+    const float *xa = X + (size_t)(m0 + arow) * ldx + akof;
     const uint16_t *wb = W + (size_t)(n0 + srow) * ldw + skof;
-    const bool a_ok = m0 + srow < M, b_ok = n0 + srow < N;
-    float4 ra[4];
+    const bool a_ok = m0 + arow < M, b_ok = n0 + srow < N;
+    // one register stage: tile k0 + 32 is on its way while tile k0 is multiplied.  (Measured and discarded: a second stage,
+    // tiles k0 + 32 and k0 + 64 in flight -- 217 -> 165 TFLOP/s on config E's shapes, 405 -> 338 at 8192 x 4096 x 4096: the
+    // rotation copies and the lost occupancy cost more than the extra tile in flight hides.)
+    float4 ra[AQ];
     uint2 rb[4];
     auto fetch = [&](int k0) {
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const int k = k0 + skof + 4 * q;
-            ra[q] = (a_ok && k < K) ? *reinterpret_cast<const float4 *>(xa + k0 + 4 * q) : make_float4(0.f, 0.f, 0.f, 0.f);
-            rb[q] = (b_ok && k < K) ? *reinterpret_cast<const uint2 *>(wb + k0 + 4 * q) : make_uint2(0u, 0u);
-        }
+        for (int q = 0; q < AQ; ++q)
+            ra[q] = (a_ok && k0 + akof + 4 * q < K) ? *reinterpret_cast<const float4 *>(xa + k0 + 4 * q) : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+            rb[q] = (b_ok && k0 + skof + 4 * q < K) ? *reinterpret_cast<const uint2 *>(wb + k0 + 4 * q) : make_uint2(0u, 0u);
     };
     auto stash = [&]() {
-        uint32_t pa[8];
+        uint32_t pa[2 * AQ];
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
+        for (int q = 0; q < AQ; ++q) {
             pa[2 * q] = bf16_bits(ra[q].x) | (bf16_bits(ra[q].y) << 16);
             pa[2 * q + 1] = bf16_bits(ra[q].z) | (bf16_bits(ra[q].w) << 16);
         }
-        uint4 *da = reinterpret_cast<uint4 *>(sA + srow * GB_LD + skof);
-        da[0] = make_uint4(pa[0], pa[1], pa[2], pa[3]);
-        da[1] = make_uint4(pa[4], pa[5], pa[6], pa[7]);
+        uint4 *da = reinterpret_cast<uint4 *>(sA + arow * GB_LD + akof);
+#pragma unroll
+        for (int q = 0; q < AQ / 2; ++q) da[q] = make_uint4(pa[4 * q], pa[4 * q + 1], pa[4 * q + 2], pa[4 * q + 3]);
         uint4 *db = reinterpret_cast<uint4 *>(sB + srow * GB_LD + skof);
         db[0] = make_uint4(rb[0].x, rb[0].y, rb[1].x, rb[1].y);
         db[1] = make_uint4(rb[2].x, rb[2].y, rb[3].x, rb[3].y);
     };
-    f32x16 acc[2][2];
+    f32x16 acc[MI][2];
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < MI; ++i)
 #pragma unroll
         for (int j = 0; j < 2; ++j)
 #pragma unroll
@@ -223,16 +234,19 @@ __global__ __launch_bounds__(256, 2) void k_gemm_bf16(const float *__restrict__ 
         const int fr = lane & 31, fh = (lane >> 5) * 8;
 #pragma unroll
         for (int ks = 0; ks < GB_K; ks += 16) {
-            bf16x8_t fa[2], fb[2];
+            bf16x8_t fa[MI], fb[2];
 #pragma unroll
-            for (int i = 0; i < 2; ++i) {
-                const uint4 va = *reinterpret_cast<const uint4 *>(sA + (wm * 64 + i * 32 + fr) * GB_LD + ks + fh);
-                const uint4 vb = *reinterpret_cast<const uint4 *>(sB + (wn * 64 + i * 32 + fr) * GB_LD + ks + fh);
+            for (int i = 0; i < MI; ++i) {
+                const uint4 va = *reinterpret_cast<const uint4 *>(sA + (wm * 32 * MI + i * 32 + fr) * GB_LD + ks + fh);
                 __builtin_memcpy(&fa[i], &va, 16);
-                __builtin_memcpy(&fb[i], &vb, 16);
             }
 #pragma unroll
-            for (int i = 0; i < 2; ++i)
+            for (int j = 0; j < 2; ++j) {
+                const uint4 vb = *reinterpret_cast<const uint4 *>(sB + (wn * 64 + j * 32 + fr) * GB_LD + ks + fh);
+                __builtin_memcpy(&fb[j], &vb, 16);
+            }
+#pragma unroll
+            for (int i = 0; i < MI; ++i)
 #pragma unroll
                 for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i], fb[j], acc[i][j], 0, 0, 0);
         }
@@ -245,10 +259,10 @@ __global__ __launch_bounds__(256, 2) void k_gemm_bf16(const float *__restrict__ 
         if (col >= N) continue;
         const float bj = bias ? bias[col] : 0.f;
 #pragma unroll
-        for (int i = 0; i < 2; ++i)
+        for (int i = 0; i < MI; ++i)
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const int row = m0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                const int row = m0 + wm * 32 * MI + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
                 if (row < M) {
                     float v = acc[i][j][r] + bj;
                     if (act == AZD_ACT_RELU) v = v > 0.f ? v : 0.f;
@@ -434,6 +448,7 @@ struct MlpEvaluator : azd_evaluator {
     float *d_wpk = nullptr;        // fragment-major weights for the asynchronous step (f32 words / bf16 halves)
     std::vector<int64_t> p_off;
     int64_t n_packed = 0;
+    int gemm_small_below = 1024; // bf16 GEMM: grids of fewer 128 x 128 tiles than this use 64 x 128 tiles (AZD_GEMM_SMALL_BELOW overrides: experiments)
 
     ~MlpEvaluator() override {
         (void)hipSetDevice(device);
@@ -483,10 +498,16 @@ struct MlpEvaluator : azd_evaluator {
             for (int l = 0; l < L; ++l) {
                 float *y = (l == L - 1) ? d_p : d_act[(size_t)l + 1];
                 const int K = dims[(size_t)l], N = dims[(size_t)l + 1];
-                dim3 grid((N + GB_N - 1) / GB_N, (batch + GB_M - 1) / GB_M);
-                k_gemm_bf16<<<grid, dim3(256), 0, st>>>(x, K, d_w16 + w_off[(size_t)l], K, y, N, batch, N, K,
-                                                        (l == L - 1) ? final_act : AZD_ACT_RELU, l < L - 1 ? 1 : 0,
-                                                        d_params + b_off[(size_t)l]);
+                const int nb = (N + GB_N - 1) / GB_N;
+                const bool small = (size_t)nb * ((batch + 127) / 128) < (size_t)gemm_small_below; // 128 x 128 tiles would leave CUs short of waves
+                if (small)
+                    k_gemm_bf16<1><<<dim3(nb, (batch + 63) / 64), dim3(256), 0, st>>>(x, K, d_w16 + w_off[(size_t)l], K, y, N, batch, N, K,
+                                                                                     (l == L - 1) ? final_act : AZD_ACT_RELU, l < L - 1 ? 1 : 0,
+                                                                                     d_params + b_off[(size_t)l]);
+                else
+                    k_gemm_bf16<2><<<dim3(nb, (batch + 127) / 128), dim3(256), 0, st>>>(x, K, d_w16 + w_off[(size_t)l], K, y, N, batch, N, K,
+                                                                                       (l == L - 1) ? final_act : AZD_ACT_RELU, l < L - 1 ? 1 : 0,
+                                                                                       d_params + b_off[(size_t)l]);
                 x = y;
             }
             AZD_HIP(hipGetLastError());
@@ -711,6 +732,7 @@ azd_evaluator *make_mlp_evaluator(int device, int max_batch, int state_dim, int 
     for (int i = 0; i < n_hidden; ++i) m->dims.push_back(hidden[i]);
     m->dims.push_back(action_dim);
     m->final_act = final_act;
+    if (const char *env = getenv("AZD_GEMM_SMALL_BELOW")) m->gemm_small_below = atoi(env);
     m->adam = *adam;
     m->max_batch = max_batch;
     int64_t off = 0;
