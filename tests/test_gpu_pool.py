@@ -165,3 +165,52 @@ def test_pool_step_reports_capacity_overflow(az):
     with pytest.raises(az.AzdError) as ei:
         opt.par_roll_out_episodes(TOL_REF, n_calls=200)
     assert ei.value.status == 4 and opt.counters()["FAILED"] > 0
+
+
+@pytest.mark.parametrize("kind", ["layered", "sequence", "ramsey_layered_mlp"])
+def test_pool_step_with_layered_states_and_sequence_paths(az, orc, kind):
+    """the pool step under the rest of the trait surface: Layered<L, Space> (the state-vector row of several chunks is
+    built in the wave's LDS and leaves as write-through stores; chunks the ring does not hold keep their contents),
+    sequence-keyed paths (no transposition table), and Layered<2, Ramsey> with the MLP through the evaluator workgroups"""
+    if kind == "ramsey_layered_mlp":
+        n, sizes, B, seed = 8, [3, 4], 40, 7
+        tol = ([6, 3, 2], 1)
+        space = az.Layered(az.RamseySpaceNoEdgeRecolor(n, sizes, [1.0, 2.0]), 2)
+        model = az.ActionModel(B, space.STATE_DIM, space.ACTION_DIM, hidden=(64, 32), seed=seed)
+        roots = space.generate_roots(seed, B, kmin=3, kmax=8)
+        opt = az.NablaOptimizer.par_new(space, roots, model, B, pool_step=True)
+        oe = orc.Engine(n, B, threads=8, ramsey=(sizes, [1.0, 2.0]), layers=2)
+        oe.new_begin(*roots)
+        oe.new_end(opt.predictions())
+        for s in range(50):
+            opt.par_roll_out_episodes(tol)
+            oe.rollout_begin(*tol)
+            assert np.array_equal(opt.state_vecs(), oe.state_vecs()), s
+            oe.rollout_end(opt.predictions())
+        assert opt.step_form() == ("pool", "")
+        for i in range(B):
+            assert_tree_equal(opt.get_tree(i), oe.export_tree(i), f"agent {i}")
+        return
+    n, B, seed, kmin, kmax = 8, 40, 3, 2, 10
+    tol = ([4, 2, 2], 1)
+    layers = 3 if kind == "layered" else 1
+    base = az.ROTModifyParentsOnce(n)
+    space = az.Layered(base, layers) if layers > 1 else base
+    path = az.ActionSet if kind == "layered" else az.ActionSequence
+    model = az.HashStreamModel(space.STATE_DIM, space.ACTION_DIM, seed, 0)
+    roots = space.generate_roots(seed, B, kmin=kmin, kmax=kmax)
+    opt = az.NablaOptimizer.par_new(space, roots, model, B, pool_step=True, path=path)
+    oe = orc.Engine(n, B, threads=8, layers=layers, path_kind=0 if kind == "layered" else 1)
+    oe.new_begin(*roots)
+    call = 0
+    oe.new_end(orc.hash_predictions(seed, 0, B, space.ACTION_DIM, call))
+    for s in range(0, 60, 6):
+        opt.par_roll_out_episodes(tol, n_calls=6)
+        for _ in range(6):
+            oe.rollout_begin(*tol)
+            call += 1
+            oe.rollout_end(orc.hash_predictions(seed, 0, B, space.ACTION_DIM, call))
+        assert np.array_equal(opt.state_vecs(), oe.state_vecs()), s
+        for i in range(B):
+            assert_tree_equal(opt.get_tree(i), oe.export_tree(i), f"step {s} agent {i}")
+    assert opt.step_form() == ("pool", "")
