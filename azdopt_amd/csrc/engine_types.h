@@ -231,6 +231,7 @@ struct PoolArgs {
     int n_eval;            // blocks [0, n_eval) are evaluator workgroups
     uint32_t eval_stride;  // floats per row of an evaluator batch in LDS
     uint32_t eval_out_off; // offset (floats) of the head's output inside a row
+    uint32_t eval_rows;    // rows an evaluator batch may hold: 16, or 32 (two MFMA row tiles per weight fragment)
 };
 
 struct PersistArgs { // argument block of the persistent step, read from device memory
