@@ -678,7 +678,8 @@ int azd_engine_create(azd_engine **out, const azd_engine_config *cfg, azd_evalua
         TRY(e->alloc(&e->pool.ctl, 1));
         TRY(e->alloc(&e->pool.ready_slots, e->pool_slot_words));
         e->pool.eval_slots = e->pool.ready_slots + (size_t)2 * azd::POOL_XCDS * qcap;
-        TRY(e->alloc(&e->pool.calls_done, B));
+        TRY(e->alloc(&e->pool.calls_done, (size_t)2 * B));
+        e->pool.join = e->pool.calls_done + B;
         TRY(e->alloc(&e->pool.pend, B));
         TRY(e->alloc(&e->pool.stamp, B));
     }
@@ -874,6 +875,12 @@ int azd_engine_par_roll_out_episodes(azd_engine *e, const uint32_t *tol, int n_t
         // populations are bound by the searchers' capacity, not by the order they are served in.  Off unless asked for.)
         pool.ready_lanes = 0;
         if (const char *env = getenv("AZD_POOL_READY_LANES")) pool.ready_lanes = atoi(env) != 0;
+        // Early post: the row leaves, and the evaluator is asked, before the wave computes the new node's cost and writes the
+        // tree back (the agent is queued again by whoever is later, PoolArgs::join).  That takes ~15 us off an agent's cycle
+        // and costs the wave a second drain of its stores (~1.5 us): +10 % where agents rarely wait for a wave (512..2048
+        // agents, gpurun r2k/e_*), -3 % where the searchers' capacity is the bound (4096 agents and beyond).
+        pool.early_post = (double)B <= 1.25 * n_search * 16; // 16 waves per searcher workgroup
+        if (const char *env = getenv("AZD_POOL_EARLY_POST")) pool.early_post = atoi(env) != 0;
         pool_blocks = n_eval + n_search;
         e->pool_eval_wgs = n_eval;
         e->pool_search_wgs = n_search;
@@ -894,7 +901,7 @@ int azd_engine_par_roll_out_episodes(azd_engine *e, const uint32_t *tol, int n_t
             if (use_pool) { // empty queues, nobody claimed, no call done
                 AZD_HIP(hipMemsetAsync(pool.ctl, 0, sizeof(azd::PoolCtl), e->stream));
                 AZD_HIP(hipMemsetAsync(pool.ready_slots, 0, e->pool_slot_words * sizeof(uint32_t), e->stream));
-                AZD_HIP(hipMemsetAsync(pool.calls_done, 0, (size_t)e->a.B * sizeof(uint32_t), e->stream));
+                AZD_HIP(hipMemsetAsync(pool.calls_done, 0, (size_t)2 * e->a.B * sizeof(uint32_t), e->stream)); // + join
             }
             e->time_begin(0);
             if (use_pool) azd::launch_pool(e->a, e->d_pargs, k, e->d_log_key, fe.params, fe.wpk, pool_blocks, dyn_stride, dyn_bytes, e->stream);

@@ -224,8 +224,11 @@ struct PoolArgs {
     uint32_t *ready_slots; // [2][POOL_XCDS][qcap]  agent + 1, 0 = empty
     uint32_t *eval_slots;  // [2][POOL_XCDS][qcap]  (agent + 1) | home XCD << 24
     int ready_lanes;       // 1: lane mode
+    int early_post;        // 1: the request for a prediction row leaves before the new node's cost is computed
     uint32_t qcap;         // power of two >= 2 * B
     uint32_t *calls_done;  // [B] calls of this launch the agent has completed
+    uint32_t *join;        // [B] behind calls_done: +1 by the wave that posted the agent's row once its own stores are out, +1 by
+                           // the evaluator once the prediction row is out; whoever brings it to an even count queues the agent
     PendRec *pend;         // [B]
     unsigned long long *stamp; // [B] diagnostic build (make PROFILE=1): when the agent was posted / its row stored
     int n_eval;            // blocks [0, n_eval) are evaluator workgroups
