@@ -640,6 +640,7 @@ int azd_engine_create(azd_engine **out, const azd_engine_config *cfg, azd_evalua
     TRY(e->alloc(&a.argmin, 1));
     TRY(e->alloc(&a.status, 1));
     if (a.layers > 1) TRY(e->alloc(&a.cur_seq, B * azd::MAX_NODE_ACTIONS));
+    TRY(e->alloc(&a.cur_stack, B * azd::PATH_STACK));
     if (dense) {
         TRY(e->alloc(&a.root_adj, B * 64));
         TRY(e->alloc(&a.cur_adj, B * 64));
@@ -879,8 +880,10 @@ int azd_engine_par_roll_out_episodes(azd_engine *e, const uint32_t *tol, int n_t
         // tree back (the agent is queued again by whoever is later, PoolArgs::join).  That takes ~15 us off an agent's cycle
         // and costs the wave a second drain of its stores (~1.5 us): +10 % where agents rarely wait for a wave (512..2048
         // agents, gpurun r2k/e_*), -3 % where the searchers' capacity is the bound (4096 agents and beyond).
-        pool.early_post = (double)B <= 1.25 * n_search * 16; // 16 waves per searcher workgroup
-        if (const char *env = getenv("AZD_POOL_EARLY_POST")) pool.early_post = atoi(env) != 0;
+        // Larger populations: only by a wave that had to wait for its agent (mode 2), which is the state of the last fifth of a
+        // launch, when the slowest chains are all that is left.
+        pool.early_post = (double)B <= 1.25 * n_search * 16 ? 1 : 2; // 16 waves per searcher workgroup
+        if (const char *env = getenv("AZD_POOL_EARLY_POST")) pool.early_post = atoi(env);
         pool_blocks = n_eval + n_search;
         e->pool_eval_wgs = n_eval;
         e->pool_search_wgs = n_search;

@@ -25,6 +25,7 @@ constexpr int SPACE_C21 = 1, SPACE_RAMSEY = 2, SPACE_DENSE = 3; // = AZD_SPACE_*
 constexpr int PRED_CHUNKS = 2;               // a node holds at most 64*PRED_CHUNKS legal actions
 constexpr int MAX_NODE_ACTIONS = 64 * PRED_CHUNKS;
 constexpr int FRONTIER_CAP = 256;            // LDS-staged cascade frontier per tree
+constexpr int PATH_STACK = 64;               // nodes of the current path kept per agent, root first (deeper levels: not kept)
 constexpr int MAX_TOL = 32;
 constexpr int NUM_COUNTERS = 32; // 0..15 public counters, 16..24 phase ticks (AZD_PHASE_PROFILE builds), 25..27 evaluator service
 
@@ -156,6 +157,9 @@ struct Arenas {
     // stored: a state of the path is the root plus a prefix of the path's actions, kept in order in cur_seq.
     int layers, S_inner;
     uint16_t *cur_seq; // [B][MAX_NODE_ACTIONS] actions of the current path in the order taken (layers > 1)
+    // The nodes of the current path, root first: the cascade that follows a terminal or a transposition visits them all
+    // (they are ancestors of the arc), and fetches their records in one round trip instead of one per level.
+    uint32_t *cur_stack; // [B][PATH_STACK]
 };
 
 // what the persistent step needs to run the evaluator inside the kernel
@@ -224,7 +228,8 @@ struct PoolArgs {
     uint32_t *ready_slots; // [2][POOL_XCDS][qcap]  agent + 1, 0 = empty
     uint32_t *eval_slots;  // [2][POOL_XCDS][qcap]  (agent + 1) | home XCD << 24
     int ready_lanes;       // 1: lane mode
-    int early_post;        // 1: the request for a prediction row leaves before the new node's cost is computed
+    int early_post;        // the request for a prediction row leaves before the new node's cost is computed: 1 always, 2 when
+                           // the wave had to wait for the agent (waves idle: latency-bound), 0 never
     uint32_t qcap;         // power of two >= 2 * B
     uint32_t *calls_done;  // [B] calls of this launch the agent has completed
     uint32_t *join;        // [B] behind calls_done: +1 by the wave that posted the agent's row once its own stores are out, +1 by

@@ -105,11 +105,11 @@ def test_pool_step_call_by_call_against_the_oracle(az, orc):
     assert np.isfinite(opt.par_update_model(5))
 
 
-@pytest.mark.parametrize("B,early_post", [(4096, "0"), (4096, "1"), (8192, None), (1024, "0")])
+@pytest.mark.parametrize("B,early_post", [(4096, "0"), (4096, "1"), (4096, "2"), (8192, None), (1024, "2")])
 def test_pool_step_full_epoch_equals_async(az, B, early_post, monkeypatch):
     """a whole epoch in one launch: 4096 agents (BASELINE config B) and 8192 (more agents than resident searcher waves:
     every agent migrates between waves and CUs of its XCD many times).  early_post: the request for a prediction row
-    leaves before / after the wave computes the new node's cost (the engine picks by population; both forced here)."""
+    leaves before / after the wave computes the new node's cost (0 never, 1 always, 2 by a wave that stood idle; the engine picks by population, all forced here)."""
     if early_post is not None:
         monkeypatch.setenv("AZD_POOL_EARLY_POST", early_post)
     n, calls = 19, 800

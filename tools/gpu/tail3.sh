@@ -1,0 +1,3 @@
+mkdir -p gpurun_out/r2k
+AZD_LIB=azdopt_amd/libazdopt_amd_prof.so timeout -k 10 200 python tools/pool_tail.py 4096 800 > gpurun_out/r2k/tail.txt 2>&1
+grep -v amdgpu gpurun_out/r2k/tail.txt

@@ -38,8 +38,8 @@ span = life.max()
 print("B %d calls %d: launch %.1f ms; agents finish at (ms): p10 %.1f p50 %.1f p90 %.1f p99 %.1f max %.1f" % (
     B, calls, span / 1e3, *[np.percentile(life, q) / 1e3 for q in (10, 50, 90, 99)], life.max() / 1e3))
 names = {0: "new nodes", 1: "terminals", 2: "transpositions", 3: "visited steps", 4: "select calls", 5: "sum deg", 6: "sum actions",
-         7: "cascade nodes", 12: "curiosity pairs", 16: "ticks search", 17: "ticks select", 18: "ticks lookup", 19: "ticks new node",
-         20: "ticks cascade", 22: "ticks lambda", 24: "ticks wait eval"}
+         7: "cascade nodes", 12: "curiosity pairs", 13: "cascade arcs", 14: "sweep nodes", 10: "max frontier", 16: "ticks search", 17: "ticks select", 18: "ticks lookup", 19: "ticks new node",
+         20: "ticks cascade", 22: "ticks lambda", 23: "ticks matching", 24: "ticks wait eval"}
 order = np.argsort(life)
 groups = {"all": order, "fastest 10%": order[: B // 10], "middle 10%": order[B * 45 // 100: B * 55 // 100], "slowest 10%": order[-(B // 10):],
           "slowest 1%": order[-(B // 100):]}
