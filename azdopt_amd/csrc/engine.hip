@@ -679,8 +679,7 @@ int azd_engine_create(azd_engine **out, const azd_engine_config *cfg, azd_evalua
         TRY(e->alloc(&e->pool.ctl, 1));
         TRY(e->alloc(&e->pool.ready_slots, e->pool_slot_words));
         e->pool.eval_slots = e->pool.ready_slots + (size_t)2 * azd::POOL_XCDS * qcap;
-        TRY(e->alloc(&e->pool.calls_done, (size_t)2 * B));
-        e->pool.join = e->pool.calls_done + B;
+        TRY(e->alloc(&e->pool.join, B));
         TRY(e->alloc(&e->pool.pend, B));
         TRY(e->alloc(&e->pool.stamp, B));
     }
@@ -904,7 +903,7 @@ int azd_engine_par_roll_out_episodes(azd_engine *e, const uint32_t *tol, int n_t
             if (use_pool) { // empty queues, nobody claimed, no call done
                 AZD_HIP(hipMemsetAsync(pool.ctl, 0, sizeof(azd::PoolCtl), e->stream));
                 AZD_HIP(hipMemsetAsync(pool.ready_slots, 0, e->pool_slot_words * sizeof(uint32_t), e->stream));
-                AZD_HIP(hipMemsetAsync(pool.calls_done, 0, (size_t)2 * e->a.B * sizeof(uint32_t), e->stream)); // + join
+                AZD_HIP(hipMemsetAsync(pool.join, 0, (size_t)e->a.B * sizeof(uint32_t), e->stream));
             }
             e->time_begin(0);
             if (use_pool) azd::launch_pool(e->a, e->d_pargs, k, e->d_log_key, fe.params, fe.wpk, pool_blocks, dyn_stride, dyn_bytes, e->stream);

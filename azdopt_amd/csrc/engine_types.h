@@ -25,7 +25,7 @@ constexpr int SPACE_C21 = 1, SPACE_RAMSEY = 2, SPACE_DENSE = 3; // = AZD_SPACE_*
 constexpr int PRED_CHUNKS = 2;               // a node holds at most 64*PRED_CHUNKS legal actions
 constexpr int MAX_NODE_ACTIONS = 64 * PRED_CHUNKS;
 constexpr int FRONTIER_CAP = 256;            // LDS-staged cascade frontier per tree
-constexpr int PATH_STACK = 64;               // nodes of the current path kept per agent, root first (deeper levels: not kept)
+constexpr int PATH_STACK = 32;               // nodes of the current path kept per agent, root first (deeper levels: not kept)
 constexpr int MAX_TOL = 32;
 constexpr int NUM_COUNTERS = 32; // 0..15 public counters, 16..24 phase ticks (AZD_PHASE_PROFILE builds), 25..27 evaluator service
 
@@ -221,7 +221,7 @@ struct PendRec { // what a call that ended on a new node leaves for the add_acti
     uint32_t pos;
     float c;
     uint32_t n_preds;
-    uint32_t home;
+    uint32_t call; // calls of this launch the agent has completed
 };
 struct PoolArgs {
     PoolCtl *ctl;
@@ -231,8 +231,7 @@ struct PoolArgs {
     int early_post;        // the request for a prediction row leaves before the new node's cost is computed: 1 always, 2 when
                            // the wave had to wait for the agent (waves idle: latency-bound), 0 never
     uint32_t qcap;         // power of two >= 2 * B
-    uint32_t *calls_done;  // [B] calls of this launch the agent has completed
-    uint32_t *join;        // [B] behind calls_done: +1 by the wave that posted the agent's row once its own stores are out, +1 by
+    uint32_t *join;        // [B] +1 by the wave that posted the agent's row once its own stores are out, +1 by
                            // the evaluator once the prediction row is out; whoever brings it to an even count queues the agent
     PendRec *pend;         // [B]
     unsigned long long *stamp; // [B] diagnostic build (make PROFILE=1): when the agent was posted / its row stored
