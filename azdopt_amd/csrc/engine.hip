@@ -851,12 +851,14 @@ int azd_engine_par_roll_out_episodes(azd_engine *e, const uint32_t *tol, int n_t
             // trees) want a few more evaluators than that ratio says: best 88-100 of 256 at 4096 agents fp32, 80 at 8192,
             // 56 at 8192 bf16 (gpurun sweeps r2c/sw_*), which the constants below reproduce
             const double eval_us_per_row = flop / (256.0 * 2400.0) / (fe.bf16 ? 1.85 : 1.0) / 0.33;
-            const double search_us_per_call = 4.65;
+            // (a Ramsey call costs the searchers less: no lambda_1, five selections per expansion against eleven; best 126 of 256
+            // for config D, 113 cost 10 %, 134 5 % -- gpurun sweep r2m/D_*)
+            const double search_us_per_call = e->a.space == azd::SPACE_RAMSEY ? 3.6 : 4.65;
             n_eval = (int)(e->n_cus * eval_us_per_row / (eval_us_per_row + search_us_per_call) + 0.5);
             // populations well beyond the searching waves keep the evaluator queues deep enough for 32-row batches (two row
             // tiles per weight fragment, where they fit the LDS), which cost an evaluator 1.2 us per row instead of 1.6:
-            // best 72 of 256 at 8192 agents fp32 (88 at 4096), 40-48 at 8192 bf16 (gpurun sweep r2h/t_*)
-            if (pool.eval_rows > 16 && B >= 6144) n_eval = (int)(n_eval * 0.82 + 0.5);
+            // best 76-84 of 256 at 8192 agents fp32 (88-92 at 4096), 50-58 at 8192 bf16 (gpurun sweeps r2m/B8_*, C_*)
+            if (pool.eval_rows > 16 && B >= 6144) n_eval = (int)(n_eval * 0.91 + 0.5);
             const int cap = (B + 15) / 16 + 1;
             n_eval = n_eval > cap ? cap : n_eval;
             n_eval = n_eval > e->n_cus / 2 ? e->n_cus / 2 : n_eval;
