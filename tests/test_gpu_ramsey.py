@@ -105,6 +105,32 @@ def test_ramsey_triangles_two_colours_every_step(az, orc):
     assert c["TERMINALS"] > 0 and c["TRANSPOSITIONS"] > 0 and c["FAILED"] == 0
 
 
+def test_ramsey_wide_cascades_with_mlp_predictions(az, orc):
+    """r44 driven by an MLP's predictions (the same rows every time a state recurs, unlike the hash stream) revisits until the
+    DAG under a root is dense: cascades then sweep levels of more than 64 ancestors -- more than one node per lane of the
+    level-parallel sweep -- and paths run deeper than the per-agent path stack.  The oracle is fed the GPU's predictions."""
+    n, sizes, B, seed, calls = 17, [4, 4], 96, 3, 800
+    tol = ([200, 200, 100, 100, 50, 50, 25, 25], 10)
+    space = az.RamseySpaceNoEdgeRecolor(n, sizes)
+    model = az.ActionModel(B, space.STATE_DIM, space.ACTION_DIM, hidden=(256, 256, 256), seed=seed)
+    colors, permitted = space.generate_roots(seed, B)
+    opt = az.NablaOptimizer.par_new(space, (colors, permitted), model, B)
+    oe = orc.Engine(n, B, threads=8, ramsey=(sizes, [1.0, 1.0]))
+    oe.new_begin(colors, permitted)
+    oe.new_end(opt.predictions())
+    for s in range(calls):
+        opt.par_roll_out_episodes(tol)
+        oe.rollout_begin(*tol)
+        oe.rollout_end(opt.predictions())
+    cg, co = opt.counters(), oe.counters()
+    for k in MAIN_CTRS:
+        assert cg[k] == co[k], (k, cg[k], co[k])
+    assert cg["MAX_FRONTIER"] > 64 and cg["MAX_DEPTH"] > 32 and cg["FAILED"] == 0, cg
+    assert np.array_equal(opt.state_vecs(), oe.state_vecs())
+    for i in range(B):
+        assert_tree_equal(opt.get_tree(i), oe.export_tree(i), f"agent {i}")
+
+
 @pytest.mark.parametrize("persistent", [True, False])
 def test_ramsey_k4_and_weights_all_branches(az, orc, persistent):
     c = run_ramsey_parity(az, orc, 9, [4, 3], [1.0, 0.5], B=48, kmin=3, kmax=8, tol=([8, 4, 2], 1), steps=120, epochs=2,
@@ -131,6 +157,7 @@ def test_ramsey_r44_reference_hyperparameters(az, orc):
     c = run_ramsey_parity(az, orc, 17, [4, 4], [1.0, 1.0], B=64, kmin=12, kmax=68, tol=tol, steps=400, epochs=1, seed=1,
                           n_obs_tol=200, check_every=100, sample=range(0, 64, 7))
     assert c["EXPANSIONS"] > 0 and c["FAILED"] == 0
+    assert c["MAX_DEPTH"] > 32, c  # deeper than the per-agent path stack (PATH_STACK): the cascade's fallback runs too
 
 
 def test_ramsey_invalid_roots_rejected(az):
