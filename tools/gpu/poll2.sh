@@ -1,7 +1,7 @@
 export TMPDIR=/tmp
 O=gpurun_out/r2n
 mkdir -p $O
-for v in _poll127 _poll190 _poll254; do
+for v in "" _ei8 _ei96; do
 export AZD_LIB=azdopt_amd/libazdopt_amd$v.so
 for rep in 1 2; do
 timeout -k 10 300 python bench.py --no-cpu-baseline > $O/b.log 2>&1; echo "B$v $(tail -1 $O/b.log | cut -c40-70)"
