@@ -38,7 +38,7 @@ span = life.max()
 print("B %d calls %d: launch %.1f ms; agents finish at (ms): p10 %.1f p50 %.1f p90 %.1f p99 %.1f max %.1f" % (
     B, calls, span / 1e3, *[np.percentile(life, q) / 1e3 for q in (10, 50, 90, 99)], life.max() / 1e3))
 names = {0: "new nodes", 1: "terminals", 2: "transpositions", 3: "visited steps", 4: "select calls", 5: "sum deg", 6: "sum actions",
-         7: "cascade nodes", 12: "curiosity pairs", 13: "cascade arcs", 14: "ticks sweep", 10: "max frontier", 11: "max depth", 21: "ticks max call", 16: "ticks search", 17: "ticks select", 18: "ticks lookup", 19: "ticks new node",
+         7: "cascade nodes", 12: "curiosity pairs", 13: "ticks sel preds", 14: "ticks sel kids", 10: "max frontier", 11: "max depth", 21: "ticks max call", 16: "ticks search", 17: "ticks select", 18: "ticks lookup", 19: "ticks new node",
          20: "ticks cascade", 22: "ticks lambda", 23: "ticks matching", 24: "ticks wait eval"}
 order = np.argsort(life)
 groups = {"all": order, "fastest 10%": order[: B // 10], "middle 10%": order[B * 45 // 100: B * 55 // 100], "slowest 10%": order[-(B // 10):],
@@ -47,7 +47,8 @@ print("%-18s" % "per agent" + "".join("%14s" % g for g in groups))
 print("%-18s" % "finish ms" + "".join("%14.1f" % (life[ix].mean() / 1e3) for ix in groups.values()))
 for k, nm in names.items():
     scale = 0.01 / 1e3 if nm.startswith("ticks") else 1.0  # ticks -> ms
-    print("%-18s" % (nm + (" ms" if nm.startswith("ticks") else "")) + "".join("%14.1f" % (d[ix, k].mean() * scale) for ix in groups.values()))
+    src = c1 if nm.startswith("max") or nm == "ticks max call" else d  # maxima are not differences
+    print("%-18s" % (nm + (" ms" if nm.startswith("ticks") else "")) + "".join("%14.1f" % (src[ix, k].mean() * scale) for ix in groups.values()))
 other = life * 1e-3 - (d[:, 16] + d[:, 24]) * 1e-5
 print("%-18s" % "rest ms" + "".join("%14.1f" % other[ix].mean() for ix in groups.values()))
 print("(rest = finish - search - waiting for an evaluator: batches in flight, waiting for a wave, add_actions)")
@@ -60,5 +61,5 @@ print("%-18s" % "finish ms" + "".join("%10.1f" % (life[i] / 1e3) for i in worst)
 print("%-18s" % "first touched ms" + "".join("%10.1f" % ((start[i] - t0) / 1e5) for i in worst))
 for k, nm in names.items():
     scale = 0.01 / 1e3 if nm.startswith("ticks") else 1.0
-    vals = c1[worst, k] if nm.startswith("max") else d[worst, k]
+    vals = c1[worst, k] if nm.startswith("max") or nm == "ticks max call" else d[worst, k]
     print("%-18s" % (nm + (" ms" if nm.startswith("ticks") else "")) + "".join("%10.1f" % (v * scale) for v in vals))
