@@ -194,7 +194,8 @@ __global__ __launch_bounds__(256, MI == 1 ? 4 : 2) void k_gemm_bf16(const float 
     const bool a_ok = m0 + arow < M, b_ok = n0 + srow < N;
     // one register stage: tile k0 + 32 is on its way while tile k0 is multiplied.  (Measured and discarded: a second stage,
     // tiles k0 + 32 and k0 + 64 in flight -- 217 -> 165 TFLOP/s on config E's shapes, 405 -> 338 at 8192 x 4096 x 4096: the
-    // rotation copies and the lost occupancy cost more than the extra tile in flight hides.)
+    // rotation copies and the lost occupancy cost more than the extra tile in flight hides.  Nor two LDS stages with one barrier
+    // per k tile, the next tile converted and written behind this tile's MFMAs: 202 -> 183 and 407 -> 353.)
     float4 ra[AQ];
     uint2 rb[4];
     auto fetch = [&](int k0) {
