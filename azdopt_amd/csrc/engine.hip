@@ -866,7 +866,10 @@ int azd_engine_par_roll_out_episodes(azd_engine *e, const uint32_t *tol, int n_t
             // tiles per weight fragment, where they fit the LDS), which cost an evaluator 1.2 us per row instead of 1.6:
             // best 76-84 of 256 at 8192 agents fp32 (88-92 at 4096), 50-58 at 8192 bf16 (gpurun sweeps r2m/B8_*, C_*)
             if (pool.eval_rows > 16 && B >= 6144) n_eval = (int)(n_eval * 0.91 + 0.5);
-            const int cap = (B + 15) / 16 + 1;
+            // small populations leave CUs free (the searchers need no more waves than twice the agents): evaluators may take
+            // them down to ~4 rows per batch -- rows then rarely queue behind a running batch (config A, 512 agents and a
+            // 2.5 MFLOP model: 33 / 64 / 128 evaluator workgroups -> 2.70 / 2.92 / 3.09 M expansions/s; gpurun r2t/A_*)
+            const int cap = (B + 3) / 4 + 1;
             n_eval = n_eval > cap ? cap : n_eval;
             n_eval = n_eval > e->n_cus / 2 ? e->n_cus / 2 : n_eval;
             n_eval = n_eval < 1 ? 1 : n_eval;
