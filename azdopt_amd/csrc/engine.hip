@@ -871,7 +871,11 @@ int azd_engine_par_roll_out_episodes(azd_engine *e, const uint32_t *tol, int n_t
             // 2.5 MFLOP model: 33 / 64 / 128 evaluator workgroups -> 2.70 / 2.92 / 3.09 M expansions/s; gpurun r2t/A_*)
             const int cap = (B + 3) / 4 + 1;
             n_eval = n_eval > cap ? cap : n_eval;
-            n_eval = n_eval > e->n_cus / 2 ? e->n_cus / 2 : n_eval;
+            {   // at most half the chip, or whatever the searchers of a small population leave
+                const int want_search = (B + 7) / 8;
+                const int most = want_search < e->n_cus / 2 ? e->n_cus - want_search : e->n_cus / 2;
+                n_eval = n_eval > most ? most : n_eval;
+            }
             n_eval = n_eval < 1 ? 1 : n_eval;
             if (const char *env = getenv("AZD_POOL_EVAL_WGS")) n_eval = atoi(env) > 0 ? atoi(env) : n_eval;
         }
