@@ -1,0 +1,75 @@
+// The reference's c21 driver (graph-state/examples/04-c21-tree.rs) from a compiled host, over include/azdopt_amd.hpp:
+// the same loop, the same hyper-parameters, the same console lines as examples/c21_tree.py.
+//
+//   g++ -O2 -std=c++17 -Iinclude examples/c21_tree.cpp -o examples/c21_tree -Lazdopt_amd -lazdopt_amd -Wl,-rpath,'$ORIGIN/../azdopt_amd'
+//   examples/c21_tree [epochs 250] [episodes 800] [batch 512] [stride 1] [seed 0] [hidden ... (default 512 1024 512)]
+//
+// Differences forced by the boundary: the `init_states` / `modify_root` closures are the seeded built-ins, and `stride`
+// calls run on the device between two looks at ArgminImprovement (stride 1 = the reference's call-by-call loop).
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
+
+#include "azdopt_amd.hpp"
+
+namespace {
+constexpr int N = 19;                                                 // 04-c21-tree.rs:36
+constexpr float C_LOWER = 2.f, C_UPPER = 5.f + 10.f;                  // :58-67 (ceil(sqrt(18)) + (19 + 1) / 2)
+constexpr float GOAL = (5.2f - C_LOWER) / (C_UPPER - C_LOWER);        // squish(5.2), :116
+
+bool process_argmin(const azdopt::C21Argmin &a) {
+    std::printf("%12.9g\tConjecture2Dot1Cost { matching: [", a.eval);
+    for (size_t i = 0; i < a.matching.size(); ++i) std::printf("%s(%d, %d)", i ? ", " : "", a.matching[i].first, a.matching[i].second);
+    std::printf("], lambda_1: %.17g }\n", a.lambda_1);
+    if (a.eval < GOAL) {
+        std::printf("state is optimal:\nparents = [");
+        for (size_t v = 0; v < a.parents.size(); ++v) std::printf("%s%d", v ? ", " : "", (int)a.parents[v]);
+        std::printf("]\n");
+        return true;
+    }
+    return false;
+}
+} // namespace
+
+int main(int argc, char **argv) {
+    const int epochs = argc > 1 ? std::atoi(argv[1]) : 250;    // :131
+    const int episodes = argc > 2 ? std::atoi(argv[2]) : 800;  // :132
+    const int batch = argc > 3 ? std::atoi(argv[3]) : 512;     // :54
+    const int stride = argc > 4 ? std::atoi(argv[4]) : 1;
+    const uint64_t seed = argc > 5 ? std::strtoull(argv[5], nullptr, 10) : 0;
+    std::vector<int> hidden;                                   // :42-52
+    for (int i = 6; i < argc; ++i) hidden.push_back(std::atoi(argv[i]));
+    if (hidden.empty()) hidden = {512, 1024, 512};
+    try {
+        const azdopt::ROTModifyParentsOnce space(N);
+        azdopt::AdamConfig adam;                               // :86-92
+        adam.lr = 1e-4f;
+        adam.l2 = 1e-6f;
+        azdopt::ActionModel model(batch, space.STATE_DIM(), space.ACTION_DIM(), hidden, adam, seed);
+        const int kmin = 5, kmax = space.ACTION_DIM() / 2;     // :85
+        const azdopt::Roots roots = space.generate_roots(seed, batch, kmin, kmax);
+        auto opt = azdopt::NablaOptimizer<azdopt::ROTModifyParentsOnce>::par_new(space, roots, model, batch);
+        if (process_argmin(opt.argmin_data())) return 0;
+        const azdopt::Tolerance n_as_tol = {{200, 50, 50}, 25}; // :134-136
+        const uint32_t n_obs_tol = 200;
+        for (int epoch = 1; epoch <= epochs; ++epoch) {
+            std::printf("==== EPOCH: %d ====\n", epoch);
+            for (int done = 0; done < episodes;) {
+                const int k = stride < episodes - done ? stride : episodes - done;
+                const int improved = opt.par_roll_out_episodes(n_as_tol, k);
+                done += k;
+                if (improved && process_argmin(opt.argmin_data())) return 0;
+            }
+            std::printf("==== EPISODE: %d ====\n", episodes);
+            const float loss = opt.par_update_model(n_obs_tol);
+            std::printf("loss: %.9g\n", loss);
+            opt.par_reset_trees_policy(seed, (uint64_t)epoch, kmin, kmax);
+        }
+        const auto form = opt.step_form();
+        std::printf("step form %d %s\n", form.first, form.second.c_str());
+    } catch (const azdopt::Error &e) {
+        std::fprintf(stderr, "azdopt error %d: %s\n", e.status(), e.what());
+        return 1;
+    }
+    return 0;
+}

@@ -111,3 +111,20 @@ def test_engine_config_validation_needs_no_device():
         assert create(**{**ramsey, **bad}) == INVALID, bad
     assert L.azd_engine_create(None, None, None) == INVALID
     assert L.azd_ramsey_generate_roots(0, 0, 0, 1, 16, 3, 5, 200, None, None) == INVALID
+
+
+def test_cpp_host_header_compiles_and_has_no_cpu_fallback(tmp_path):
+    """include/azdopt_amd.hpp (the compiled-host mirror of NablaOptimizer / ActionModel) compiles warning-free against the
+    C ABI, links with the library, and its example driver fails loudly where there is no device"""
+    import os
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = tmp_path / "c21_tree"
+    subprocess.run(["g++", "-O1", "-std=c++17", "-Wall", "-Wextra", "-Werror", "-I" + os.path.join(root, "include"),
+                    os.path.join(root, "examples", "c21_tree.cpp"), "-o", str(exe), "-L" + os.path.join(root, "azdopt_amd"), "-lazdopt_amd",
+                    "-Wl,-rpath," + os.path.join(root, "azdopt_amd")], check=True, timeout=300)
+    import azdopt_amd as az
+    if az.device_count() > 0:
+        pytest.skip("a GPU is present: tests/test_gpu_examples.py runs the driver")
+    r = subprocess.run([str(exe), "1", "1", "16"], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 1 and "no gfx950 device" in r.stderr, (r.returncode, r.stderr)

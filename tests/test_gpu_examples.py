@@ -36,3 +36,41 @@ def test_ramsey_driver_writes_the_reference_scalars(tmp_path):
     ev = sinks.read_events(out / "tfevents-losses")
     tags = [t for e in ev for t, _ in e[3]]
     assert tags.count("loss") == 2 and {"clique_counts/0", "clique_counts/1"} <= set(tags)
+
+
+def test_cpp_host_drives_the_same_engine(tmp_path):
+    """examples/c21_tree.cpp over include/azdopt_amd.hpp (a compiled host on the C ABI) and the Python host run the same
+    two epochs: same losses, same best evaluation and lambda_1 line by line"""
+    import azdopt_amd as az
+    exe = tmp_path / "c21_tree"
+    subprocess.run(["g++", "-O1", "-std=c++17", "-I" + os.path.join(ROOT, "include"), os.path.join(ROOT, "examples", "c21_tree.cpp"), "-o", str(exe),
+                    "-L" + os.path.join(ROOT, "azdopt_amd"), "-lazdopt_amd", "-Wl,-rpath," + os.path.join(ROOT, "azdopt_amd")], check=True, timeout=300)
+    epochs, episodes, batch, stride, seed, hidden = 2, 60, 64, 20, 3, [64, 64]
+    r = subprocess.run([str(exe), str(epochs), str(episodes), str(batch), str(stride), str(seed)] + [str(h) for h in hidden],
+                       capture_output=True, text=True, timeout=300, check=True)
+    lines = r.stdout.splitlines()
+    # the same loop through the Python host
+    space = az.ROTModifyParentsOnce(19)
+    model = az.ActionModel(batch, space.STATE_DIM, space.ACTION_DIM, hidden=hidden, lr=1e-4, betas=(0.9, 0.999), eps=1e-8, l2=1e-6, seed=seed)
+    kmin, kmax = 5, space.ACTION_DIM // 2
+    opt = az.NablaOptimizer.par_new(space, space.generate_roots(seed, batch, kmin=kmin, kmax=kmax), model, batch)
+    want = []
+
+    def show(a):
+        want.append("%12.9g\tConjecture2Dot1Cost { matching: [%s], lambda_1: %.17g }" % (
+            a.eval, ", ".join("(%d, %d)" % tuple(p) for p in a.cost["matching"]), a.cost["lambda_1"]))
+
+    show(opt.argmin_data())
+    for epoch in range(1, epochs + 1):
+        want.append("==== EPOCH: %d ====" % epoch)
+        done = 0
+        while done < episodes:
+            improved = opt.par_roll_out_episodes(([200, 50, 50], 25), n_calls=stride)
+            done += stride
+            if improved:
+                show(opt.argmin_data())
+        want.append("==== EPISODE: %d ====" % episodes)
+        want.append("loss: %.9g" % opt.par_update_model(200))
+        opt.par_reset_trees_policy(seed, epoch, kmin, kmax)
+    assert lines[:len(want)] == want, "\n".join(lines[:len(want)]) + "\n---\n" + "\n".join(want)
+    assert lines[len(want)].startswith("step form ")
