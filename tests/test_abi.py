@@ -119,10 +119,11 @@ def test_cpp_host_header_compiles_and_has_no_cpu_fallback(tmp_path):
     import os
     import subprocess
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    exe = tmp_path / "c21_tree"
-    subprocess.run(["g++", "-O1", "-std=c++17", "-Wall", "-Wextra", "-Werror", "-I" + os.path.join(root, "include"),
-                    os.path.join(root, "examples", "c21_tree.cpp"), "-o", str(exe), "-L" + os.path.join(root, "azdopt_amd"), "-lazdopt_amd",
-                    "-Wl,-rpath," + os.path.join(root, "azdopt_amd")], check=True, timeout=300)
+    for name in ("ramsey", "c21_tree"):
+        exe = tmp_path / name
+        subprocess.run(["g++", "-O1", "-std=c++17", "-Wall", "-Wextra", "-Werror", "-I" + os.path.join(root, "include"),
+                        os.path.join(root, "examples", name + ".cpp"), "-o", str(exe), "-L" + os.path.join(root, "azdopt_amd"), "-lazdopt_amd",
+                        "-Wl,-rpath," + os.path.join(root, "azdopt_amd")], check=True, timeout=300)
     import azdopt_amd as az
     if az.device_count() > 0:
         pytest.skip("a GPU is present: tests/test_gpu_examples.py runs the driver")

@@ -74,3 +74,41 @@ def test_cpp_host_drives_the_same_engine(tmp_path):
         opt.par_reset_trees_policy(seed, epoch, kmin, kmax)
     assert lines[:len(want)] == want, "\n".join(lines[:len(want)]) + "\n---\n" + "\n".join(want)
     assert lines[len(want)].startswith("step form ")
+
+
+def test_cpp_host_ramsey_driver_matches_the_python_host(tmp_path):
+    """examples/ramsey.cpp (02-r44.rs over include/azdopt_amd.hpp) against the same loop through the Python host"""
+    import azdopt_amd as az
+    exe = tmp_path / "ramsey"
+    subprocess.run(["g++", "-O1", "-std=c++17", "-I" + os.path.join(ROOT, "include"), os.path.join(ROOT, "examples", "ramsey.cpp"), "-o", str(exe),
+                    "-L" + os.path.join(ROOT, "azdopt_amd"), "-lazdopt_amd", "-Wl,-rpath," + os.path.join(ROOT, "azdopt_amd")], check=True, timeout=300)
+    epochs, episodes, batch, stride, seed, hidden = 2, 40, 32, 10, 4, [64]
+    r = subprocess.run([str(exe), "r44", str(epochs), str(episodes), str(batch), str(stride), str(seed)] + [str(h) for h in hidden],
+                       capture_output=True, text=True, timeout=300, check=True)
+    lines = r.stdout.splitlines()
+    space = az.RamseySpaceNoEdgeRecolor(17, [4, 4], [1.0, 1.0])
+    model = az.ActionModel(batch, space.STATE_DIM, space.ACTION_DIM, hidden=hidden, lr=1e-4, l2=1e-6, seed=seed)
+    kmin, kmax = 12, space.default_permitted_range()[1]
+    caps = dict(node_capacity=episodes * 2 + 64, arc_capacity=episodes * 3 + 64, prediction_capacity=(episodes + 1) * kmax + 128)
+    opt = az.NablaOptimizer.par_new(space, space.generate_roots(seed, batch, kmin=kmin, kmax=kmax), model, batch, **caps)
+    tol = ([200, 200, 100, 100, 50, 50, 25, 25], 10)
+    want = []
+
+    def show(a):
+        want.append("%.9g\tTotalCounts([%s])" % (a.eval, ", ".join(str(int(x)) for x in a.cost["clique_counts"])))
+
+    show(opt.argmin_data())
+    for epoch in range(1, epochs + 1):
+        want.append("==== EPOCH: %d ====" % epoch)
+        done = 0
+        while done < episodes:
+            if opt.par_roll_out_episodes(tol, n_calls=stride):
+                show(opt.argmin_data())
+            done += stride
+        want.append("==== EPISODE: %d ====" % episodes)
+        want.append("loss: %.9g" % opt.par_update_model(200))
+        opt.par_reset_trees_policy(seed, epoch, kmin, kmax)
+    # (a root whose colouring has no monochromatic clique makes h_sa = 1 - c*/c a NaN, and with it the loss, in the reference
+    # too -- its drivers stop there; printf spells the sign of a NaN, Python does not)
+    lines = [x.replace("-nan", "nan") for x in lines]
+    assert lines == want, "\n".join(lines) + "\n---\n" + "\n".join(want)
