@@ -7,6 +7,8 @@
 //   ------------------------------------------------------------------------   ------------------------------------------
 //   nabla/model/mod.rs:4-8      trait NablaModel { write_predictions,          azdopt::NablaModel (ActionModel, TrivialModel,
 //                               update_model }                                  HashStreamModel)
+//                               impl NablaModel for a host's own type          azdopt::HostModel (called across the boundary at
+//                                                                               optimizer/mod.rs:72, :175-176, :270-277, :348)
 //   nabla/model/dfdx.rs:36-53   ActionModel::new(model, cfg)                   azdopt::ActionModel(max_batch, S, A, hidden, adam)
 //   nabla/optimizer/mod.rs:39   NablaOptimizer::par_new(space, init_states,    azdopt::NablaOptimizer::par_new(space, roots,
 //                               model, batch, ...)                              model, batch)
@@ -180,6 +182,20 @@ public:
     }
 };
 
+// A NablaModel that lives on the HOST side of the boundary: any C++ type with the trait's two methods over host slices.  The
+// optimizer then runs every call split at the model call (the C ABI's *_begin / *_end pairs, cut at optimizer/mod.rs:72,
+// :175-176, :348): state vectors come out, the host's predictions go back in.  One launch per phase and a host round trip
+// per call -- the device-resident evaluators above are the fast path; this is the seam for a model the library does not have.
+class HostModel {
+public:
+    virtual ~HostModel() = default;
+    // write_predictions(&mut self, x: &[f32], predictions: &mut [f32]): batch rows of STATE / ACTION floats; `predictions`
+    // holds the previous call's rows on entry (TrivialModel, model/mod.rs:10-23, leaves them as they are)
+    virtual void write_predictions(int batch, const float *x, float *predictions) = 0;
+    // update_model(&mut self, x, observations, action_weights) -> loss (model/mod.rs:6-7)
+    virtual float update_model(int batch, const float *x, const float *observations, const float *action_weights) = 0;
+};
+
 // ---------------------------------------------------------------- ArgminData (log.rs:1-11)
 struct C21Argmin {
     std::vector<uint8_t> parents;                  // state: the rooted tree
@@ -205,7 +221,10 @@ class NablaOptimizer {
 public:
     NablaOptimizer(const NablaOptimizer &) = delete;
     NablaOptimizer &operator=(const NablaOptimizer &) = delete;
-    NablaOptimizer(NablaOptimizer &&o) noexcept : space_(o.space_), model_(o.model_), h_(o.h_), batch_(o.batch_) { o.h_ = nullptr; }
+    NablaOptimizer(NablaOptimizer &&o) noexcept
+        : space_(o.space_), model_(o.model_), host_(o.host_), h_(o.h_), batch_(o.batch_), sv_(std::move(o.sv_)), pred_(std::move(o.pred_)) {
+        o.h_ = nullptr;
+    }
     ~NablaOptimizer() {
         if (h_) azd_engine_destroy(h_);
     }
@@ -233,23 +252,79 @@ public:
         return opt;
     }
 
-    // optimizer/mod.rs:121-191, n_calls times back to back on the device; returns how many calls improved the argmin
+    // the same with a model on the host side of the boundary (HostModel): the engine has no evaluator and every call is split
+    // at the model call
+    static NablaOptimizer par_new(const Space &space, const Roots &roots, HostModel &model, int batch, int device = 0, uint64_t first_agent = 0,
+                                  int node_capacity = 0, int arc_capacity = 0, int prediction_capacity = 0) {
+        azd_engine_config cfg = {};
+        space.configure(cfg);
+        cfg.batch = batch;
+        cfg.device = device;
+        cfg.node_capacity = node_capacity;
+        cfg.arc_capacity = arc_capacity;
+        cfg.prediction_capacity = prediction_capacity;
+        cfg.first_agent = first_agent;
+        azd_engine *h = nullptr;
+        check(azd_engine_create(&h, &cfg, nullptr), "NablaOptimizer::par_new (engine)");
+        NablaOptimizer opt(space, h, batch);
+        opt.host_ = &model;
+        opt.sv_.assign((size_t)batch * space.STATE_DIM(), 0.f);
+        opt.pred_.assign((size_t)batch * space.ACTION_DIM(), 0.f);
+        check(azd_engine_par_new_begin(h, roots.state.data(), roots.permitted.data()), "par_new_begin");
+        opt.host_predictions();
+        check(azd_engine_par_new_end(h, opt.pred_.data()), "par_new_end");
+        return opt;
+    }
+
+    // optimizer/mod.rs:121-191, n_calls times back to back on the device (a HostModel: call by call through the host); returns
+    // how many calls improved the argmin
     int par_roll_out_episodes(const Tolerance &n_as_tol, int n_calls = 1) {
         int improved = 0;
-        check(azd_engine_par_roll_out_episodes(h_, n_as_tol.table.data(), (int)n_as_tol.table.size(), n_as_tol.otherwise, n_calls, &improved), "par_roll_out_episodes");
+        if (!host_) {
+            check(azd_engine_par_roll_out_episodes(h_, n_as_tol.table.data(), (int)n_as_tol.table.size(), n_as_tol.otherwise, n_calls, &improved), "par_roll_out_episodes");
+            return improved;
+        }
+        for (int i = 0; i < n_calls; ++i) {
+            int one = 0;
+            check(azd_engine_roll_out_begin(h_, n_as_tol.table.data(), (int)n_as_tol.table.size(), n_as_tol.otherwise), "roll_out_begin");
+            host_predictions();
+            check(azd_engine_roll_out_end(h_, pred_.data(), &one), "roll_out_end");
+            improved += one;
+        }
         return improved;
     }
     // optimizer/mod.rs:249-281; returns the loss
     float par_update_model(uint32_t n_obs_tol) {
         float loss = 0.f;
-        check(azd_engine_par_update_model(h_, n_obs_tol, &loss), "par_update_model");
-        return loss;
+        if (!host_) {
+            check(azd_engine_par_update_model(h_, n_obs_tol, &loss), "par_update_model");
+            return loss;
+        }
+        std::vector<float> obs(pred_.size()), w(pred_.size());
+        check(azd_engine_observe(h_, n_obs_tol, sv_.data(), obs.data(), w.data()), "observe");
+        return host_->update_model(batch_, sv_.data(), obs.data(), w.data());
     }
     // optimizer/mod.rs:284-360 with the caller's modify_root results ...
-    void par_reset_trees(const Roots &roots) { check(azd_engine_par_reset_trees(h_, roots.state.data(), roots.permitted.data()), "par_reset_trees"); }
+    void par_reset_trees(const Roots &roots) {
+        if (!host_) {
+            check(azd_engine_par_reset_trees(h_, roots.state.data(), roots.permitted.data()), "par_reset_trees");
+            return;
+        }
+        check(azd_engine_reset_begin(h_, roots.state.data(), roots.permitted.data()), "reset_begin");
+        host_predictions();
+        check(azd_engine_reset_end(h_, pred_.data()), "reset_end");
+    }
     // ... or with the drivers' modify_root policy (04-c21-tree.rs:172-206, 02-r44.rs:196-228) evaluated on the device
     void par_reset_trees_policy(uint64_t seed, uint64_t epoch, int kmin, int kmax) {
-        check(azd_engine_par_reset_trees_policy(h_, seed, epoch, kmin, kmax), "par_reset_trees_policy");
+        if (!host_) {
+            check(azd_engine_par_reset_trees_policy(h_, seed, epoch, kmin, kmax), "par_reset_trees_policy");
+            return;
+        }
+        Roots r; // the policy on the device, the reset through the host's model
+        r.state.resize((size_t)batch_ * root_bytes(space_));
+        r.permitted.resize((size_t)batch_ * space_.KEY_WORDS());
+        check(azd_engine_modify_roots_dev(h_, seed, epoch, kmin, kmax, r.state.data(), r.permitted.data()), "modify_roots");
+        par_reset_trees(r);
     }
     // optimizer/mod.rs:361
     auto argmin_data() { return argmin_of(space_); }
@@ -271,6 +346,13 @@ public:
 
 private:
     NablaOptimizer(const Space &space, NablaModel &model, azd_engine *h, int batch) : space_(space), model_(&model), h_(h), batch_(batch) {}
+    NablaOptimizer(const Space &space, azd_engine *h, int batch) : space_(space), h_(h), batch_(batch) {}
+    static int root_bytes(const ROTModifyParentsOnce &sp) { return sp.n(); }
+    static int root_bytes(const RamseySpaceNoEdgeRecolor &sp) { return sp.E(); }
+    void host_predictions() { // the model call of optimizer/mod.rs:72 / :175-176 / :348 on the host side
+        check(azd_engine_read_state_vecs(h_, sv_.data()), "read_state_vecs");
+        host_->write_predictions(batch_, sv_.data(), pred_.data());
+    }
     C21Argmin argmin_of(const ROTModifyParentsOnce &sp) {
         azd_argmin a;
         check(azd_engine_argmin_data(h_, &a), "argmin_data");
@@ -297,9 +379,11 @@ private:
         return r;
     }
     Space space_;
-    NablaModel *model_;
+    NablaModel *model_ = nullptr;
+    HostModel *host_ = nullptr;
     azd_engine *h_;
     int batch_;
+    std::vector<float> sv_, pred_; // HostModel: state vectors out, predictions in (they persist from call to call)
 };
 
 } // namespace azdopt

@@ -119,10 +119,10 @@ def test_cpp_host_header_compiles_and_has_no_cpu_fallback(tmp_path):
     import os
     import subprocess
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    for name in ("ramsey", "c21_tree"):
-        exe = tmp_path / name
+    for src in (("tests", "cpp", "host_model.cpp"), ("examples", "ramsey.cpp"), ("examples", "c21_tree.cpp")):
+        exe = tmp_path / src[-1][:-4]
         subprocess.run(["g++", "-O1", "-std=c++17", "-Wall", "-Wextra", "-Werror", "-I" + os.path.join(root, "include"),
-                        os.path.join(root, "examples", name + ".cpp"), "-o", str(exe), "-L" + os.path.join(root, "azdopt_amd"), "-lazdopt_amd",
+                        os.path.join(root, *src), "-o", str(exe), "-L" + os.path.join(root, "azdopt_amd"), "-lazdopt_amd",
                         "-Wl,-rpath," + os.path.join(root, "azdopt_amd")], check=True, timeout=300)
     import azdopt_amd as az
     if az.device_count() > 0:

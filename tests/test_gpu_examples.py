@@ -112,3 +112,45 @@ def test_cpp_host_ramsey_driver_matches_the_python_host(tmp_path):
     # too -- its drivers stop there; printf spells the sign of a NaN, Python does not)
     lines = [x.replace("-nan", "nan") for x in lines]
     assert lines == want, "\n".join(lines) + "\n---\n" + "\n".join(want)
+
+
+def test_cpp_host_model_seam_matches_the_python_host(tmp_path):
+    """a NablaModel on the host side of the boundary (azdopt::HostModel in include/azdopt_amd.hpp; tests/cpp/host_model.cpp)
+    against the same model fed through the Python host's *_begin / *_end calls"""
+    import numpy as np
+
+    import azdopt_amd as az
+    exe = tmp_path / "host_model"
+    subprocess.run(["g++", "-O1", "-std=c++17", "-Wall", "-Wextra", "-Werror", "-I" + os.path.join(ROOT, "include"),
+                    os.path.join(ROOT, "tests", "cpp", "host_model.cpp"), "-o", str(exe), "-L" + os.path.join(ROOT, "azdopt_amd"), "-lazdopt_amd",
+                    "-Wl,-rpath," + os.path.join(ROOT, "azdopt_amd")], check=True, timeout=300)
+    batch, calls, seed = 24, 30, 2
+    r = subprocess.run([str(exe), str(batch), str(calls)], capture_output=True, text=True, timeout=300, check=True)
+    space = az.ROTModifyParentsOnce(13)
+    S, A = space.STATE_DIM, space.ACTION_DIM
+    kmin, kmax = 3, A // 2
+
+    def predict(sv):
+        nz = (sv != 0).sum(axis=1).astype(np.int64)
+        a = np.arange(A, dtype=np.int64)
+        return (((a[None, :] * 7 + nz[:, None] * 13) % 97).astype(np.float32) / np.float32(97.0)).astype(np.float32)
+
+    opt = az.NablaOptimizer(space, None, batch)
+    opt.par_new_begin(*space.generate_roots(seed, batch, kmin=kmin, kmax=kmax))
+    opt.par_new_end(predict(opt.state_vecs()))
+    want = []
+    for epoch in range(2):
+        improved = 0
+        for _ in range(calls):
+            opt.roll_out_begin(([8, 4, 2], 1))
+            improved += opt.roll_out_end(predict(opt.state_vecs()))
+        a = opt.argmin_data()
+        want.append("improved %d eval %.9g lambda_1 %.17g matching %d" % (improved, a.eval, a.cost["lambda_1"], len(a.cost["matching"])))
+        sv, obs, w = opt.observe(3)
+        want.append("loss %.9g" % np.float32((w != 0).sum()))
+        roots = opt.modify_roots(seed, epoch, kmin, kmax, device=True)
+        opt.reset_begin(*roots)
+        opt.reset_end(predict(opt.state_vecs()))
+    c = opt.counters()
+    want.append("expansions %d transpositions %d terminals %d" % (c["EXPANSIONS"], c["TRANSPOSITIONS"], c["TERMINALS"]))
+    assert r.stdout.splitlines() == want, r.stdout + "\n---\n" + "\n".join(want)
