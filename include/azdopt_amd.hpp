@@ -304,6 +304,14 @@ public:
         check(azd_engine_observe(h_, n_obs_tol, sv_.data(), obs.data(), w.data()), "observe");
         return host_->update_model(batch_, sv_.data(), obs.data(), w.data());
     }
+    // par_update_model for a population sharded over several GPUs, one process and engine per GPU: the
+    // training triples are all-gathered over RCCL (`nccl_comm` = the caller's ncclComm_t) and every rank takes the same
+    // optimiser step on the pooled rows; the model must have been created with max_batch >= batch * world size
+    float par_update_model_sharded(uint32_t n_obs_tol, void *nccl_comm) {
+        float loss = 0.f;
+        check(azd_engine_par_update_model_sharded(h_, n_obs_tol, nccl_comm, &loss), "par_update_model_sharded");
+        return loss;
+    }
     // optimizer/mod.rs:284-360 with the caller's modify_root results ...
     void par_reset_trees(const Roots &roots) {
         if (!host_) {
