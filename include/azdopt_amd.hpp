@@ -24,6 +24,7 @@
 // over-full arena, a CUDA error), these throw azdopt::Error carrying the AZD_ERR_* status; nothing falls back to the CPU.
 #pragma once
 #include <cstdint>
+#include <cstring>
 #include <stdexcept>
 #include <string>
 #include <utility>
@@ -121,6 +122,38 @@ private:
     std::vector<float> weights_;
 };
 
+// Connected graphs on N <= 64 vertices, AddOrDeleteEdge actions, every edge slot modified at most once (BASELINE configs[4],
+// N = 50).  BUILD-DEFINED: the reference has the pieces (connected_bitset_graph/mod.rs, bitset_graph/space/action.rs:4-27,
+// STATE = E + ACTION + 1 at 05-ah.rs:39-40) but no live NablaStateActionSpace over general graphs; see azdopt_amd.h.
+class DenseGraphSpace {
+public:
+    explicit DenseGraphSpace(int n, double p = 0.2) : n_(n), p_(p) {}
+    int n() const { return n_; }
+    int E() const { return n_ * (n_ - 1) / 2; }
+    int STATE_DIM() const { return azd_dense_state_dim(n_); }
+    int ACTION_DIM() const { return azd_dense_action_dim(n_); }
+    int KEY_WORDS() const { return azd_dense_key_words(n_); }
+    // a connected G(n, p) per root and k in [kmin, kmax] modifiable edge slots; `state` holds the neighbourhood bitsets
+    // (8 n bytes per root)
+    Roots generate_roots(uint64_t seed, int count, int kmin, int kmax, uint64_t first_agent = 0, uint64_t epoch = 0) const {
+        Roots r;
+        std::vector<uint64_t> adj((size_t)count * n_);
+        r.permitted.resize((size_t)count * KEY_WORDS());
+        check(azd_dense_generate_roots(seed, epoch, first_agent, count, n_, kmin, kmax, p_, adj.data(), r.permitted.data()), "generate_roots");
+        r.state.resize(adj.size() * 8);
+        std::memcpy(r.state.data(), adj.data(), r.state.size());
+        return r;
+    }
+    void configure(azd_engine_config &cfg) const {
+        cfg.space_id = AZD_SPACE_DENSE;
+        cfg.n = n_;
+    }
+
+private:
+    int n_;
+    double p_;
+};
+
 // ---------------------------------------------------------------- models (NablaModel, nabla/model/mod.rs:4-8)
 class NablaModel {
 public:
@@ -210,6 +243,16 @@ struct RamseyArgmin {
     std::vector<uint8_t> colors;
     std::vector<uint64_t> permitted;
     std::vector<int> clique_counts; // cost: TotalCounts
+    float eval;
+    int agent;
+    uint32_t node;
+};
+
+struct DenseArgmin {
+    std::vector<uint64_t> adj;       // state: neighbourhood bitsets
+    std::vector<uint64_t> permitted; // ... and the edge slots still modifiable
+    double lambda_1;                 // cost: Conjecture2Dot1Cost { lambda_1, matching number }
+    int matching_number;
     float eval;
     int agent;
     uint32_t node;
@@ -357,6 +400,7 @@ private:
     NablaOptimizer(const Space &space, azd_engine *h, int batch) : space_(space), h_(h), batch_(batch) {}
     static int root_bytes(const ROTModifyParentsOnce &sp) { return sp.n(); }
     static int root_bytes(const RamseySpaceNoEdgeRecolor &sp) { return sp.E(); }
+    static int root_bytes(const DenseGraphSpace &sp) { return 8 * sp.n(); }
     void host_predictions() { // the model call of optimizer/mod.rs:72 / :175-176 / :348 on the host side
         check(azd_engine_read_state_vecs(h_, sv_.data()), "read_state_vecs");
         host_->write_predictions(batch_, sv_.data(), pred_.data());
@@ -381,6 +425,19 @@ private:
         r.colors.assign(a.colors, a.colors + sp.E());
         r.permitted.assign(a.permitted, a.permitted + (sp.E() + 63) / 64);
         r.clique_counts.assign(a.totals, a.totals + sp.C());
+        r.eval = a.eval;
+        r.agent = a.agent;
+        r.node = a.node;
+        return r;
+    }
+    DenseArgmin argmin_of(const DenseGraphSpace &sp) {
+        azd_dense_argmin a;
+        check(azd_engine_dense_argmin_data(h_, &a), "argmin_data");
+        DenseArgmin r;
+        r.adj.assign(a.adj, a.adj + sp.n());
+        r.permitted.assign(a.permitted, a.permitted + sp.KEY_WORDS());
+        r.lambda_1 = a.lambda_1;
+        r.matching_number = a.matching_size;
         r.eval = a.eval;
         r.agent = a.agent;
         r.node = a.node;

@@ -44,6 +44,14 @@ int main(int argc, char **argv) {
         const auto c = opt.counters();
         std::printf("expansions %llu transpositions %llu terminals %llu\n", (unsigned long long)c[AZD_CTR_EXPANSIONS],
                     (unsigned long long)c[AZD_CTR_TRANSPOSITIONS], (unsigned long long)c[AZD_CTR_TERMINALS]);
+        // the dense-graph space (BASELINE configs[4]) with a model on the device
+        const azdopt::DenseGraphSpace dense(12, 0.3);
+        azdopt::ActionModel mlp(batch, dense.STATE_DIM(), dense.ACTION_DIM(), {64}, azdopt::AdamConfig(), seed);
+        auto dopt = azdopt::NablaOptimizer<azdopt::DenseGraphSpace>::par_new(dense, dense.generate_roots(seed, batch, 4, 20), mlp, batch);
+        const int dimp = dopt.par_roll_out_episodes({{20, 10, 5}, 3}, calls);
+        const auto da = dopt.argmin_data();
+        std::printf("dense improved %d eval %.9g lambda_1 %.17g matching %d loss %.9g\n", dimp, da.eval, da.lambda_1, da.matching_number,
+                    dopt.par_update_model(3));
     } catch (const azdopt::Error &e) {
         std::fprintf(stderr, "azdopt error %d: %s\n", e.status(), e.what());
         return 1;

@@ -153,4 +153,11 @@ def test_cpp_host_model_seam_matches_the_python_host(tmp_path):
         opt.reset_end(predict(opt.state_vecs()))
     c = opt.counters()
     want.append("expansions %d transpositions %d terminals %d" % (c["EXPANSIONS"], c["TRANSPOSITIONS"], c["TERMINALS"]))
+    dense = az.DenseGraphSpace(12, 0.3)
+    mlp = az.ActionModel(batch, dense.STATE_DIM, dense.ACTION_DIM, hidden=[64], seed=seed)
+    dopt = az.NablaOptimizer.par_new(dense, dense.generate_roots(seed, batch, kmin=4, kmax=20), mlp, batch)
+    dimp = dopt.par_roll_out_episodes(([20, 10, 5], 3), n_calls=calls)
+    da = dopt.argmin_data()
+    want.append("dense improved %d eval %.9g lambda_1 %.17g matching %d loss %.9g" % (
+        dimp, da.eval, da.cost["lambda_1"], len(da.cost["matching"]), dopt.par_update_model(3)))
     assert r.stdout.splitlines() == want, r.stdout + "\n---\n" + "\n".join(want)
