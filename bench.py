@@ -2,11 +2,13 @@
 """bench.py -- node-expansions/s of the c21 self-play hot path on N MI355X (one process per GPU).
 
 A "step" is one NablaOptimizer::par_roll_out_episodes call over the whole agent population
-(select / expand / backup + the MLP forward + add_actions + argmin), executed by the CU-resident
-persistent kernel k_async (16 agents per workgroup; an agent waiting for its prediction row serves the
-workgroup's evaluator on the matrix cores; --barrier-step selects the lock-step form k_persist).  Every
-EPOCH_CALLS steps the epoch boundary of the reference driver (04-c21-tree.rs:163-207:
-par_update_model, modify_root policy, par_reset_trees) runs INSIDE the timed region.
+(select / expand / backup + the MLP forward + add_actions + argmin).  From 256 agents the engine runs it as the
+pool step k_pool (pool_step.inc): searcher workgroups of 16 independent waves pull ready agents from per-XCD
+queues, evaluator workgroups on CUs of their own pull batches of posted rows and run the MLP on the matrix
+cores; below that as k_async (16 agents per workgroup, a waiting agent serves the workgroup's evaluator).
+--step async / barrier force the other CU-resident forms.  Every EPOCH_CALLS steps the epoch boundary of the
+reference driver (04-c21-tree.rs:163-207: par_update_model, modify_root policy, par_reset_trees) runs INSIDE
+the timed region.
 
 Default workload (BASELINE.json configs[1] = --config B): c21 space N = 19 (STATE 304, ACTION 152), 4096 agents
 per GPU, fp32 MLP 304-256-256-256-152 (ReLU x3, Sigmoid), n_as_tol = [200, 50, 50] / 25, n_obs_tol = 200,

@@ -251,7 +251,8 @@ typedef struct azd_ramsey_argmin {
 /* ArgminData for the dense-graph space: the graph, its open slots, Conjecture2Dot1Cost */
 typedef struct azd_dense_argmin {
     uint64_t adj[64];
-    uint64_t permitted[40];    /* edge slots still modifiable */
+    uint64_t permitted[40];    /* BITMAP over the E edge slots (colex positions) still modifiable: (E + 63) / 64 words
+                                * (32 at AZD_DENSE_MAX_N), NOT an action-id set of azd_dense_key_words() words */
     double lambda_1;
     int32_t matching_size;
     float eval;

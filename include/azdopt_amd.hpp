@@ -435,7 +435,11 @@ private:
         check(azd_engine_dense_argmin_data(h_, &a), "argmin_data");
         DenseArgmin r;
         r.adj.assign(a.adj, a.adj + sp.n());
-        r.permitted.assign(a.permitted, a.permitted + sp.KEY_WORDS());
+        // `permitted` is a bitmap over the E edge SLOTS (colex positions) still open, not an action-id set: (E + 63) / 64 words
+        const int slot_words = (sp.E() + 63) / 64;
+        static_assert(sizeof(a.permitted) / sizeof(a.permitted[0]) >= (AZD_DENSE_MAX_N * (AZD_DENSE_MAX_N - 1) / 2 + 63) / 64,
+                      "azd_dense_argmin::permitted must hold a slot bitmap at AZD_DENSE_MAX_N");
+        r.permitted.assign(a.permitted, a.permitted + slot_words);
         r.lambda_1 = a.lambda_1;
         r.matching_number = a.matching_size;
         r.eval = a.eval;
