@@ -61,6 +61,11 @@ struct TrivialEvaluator : azd_evaluator { // TrivialModel, model/mod.rs:10-23
 
 struct HashStreamEvaluator : azd_evaluator {
     uint64_t seed = 0, first_agent = 0;
+    bool via_pool = false; // the pool step serves the rows from its evaluator workgroups (FusedEval kind 4: test harness)
+    int debug_serve_from_pool(int on) override {
+        via_pool = on != 0;
+        return AZD_OK;
+    }
     int write_predictions_dev(int batch, const float *, float *d_p, hipStream_t st) override {
         launch_hash_predictions(d_p, batch, action_dim, seed, first_agent, calls, st);
         calls += 1;
@@ -69,10 +74,9 @@ struct HashStreamEvaluator : azd_evaluator {
     }
     bool fused_desc(FusedEval *f) override {
         memset(f, 0, sizeof(*f));
-        f->kind = 2;
+        f->kind = via_pool ? 4 : 2;
         f->seed = seed;
         f->first_agent = first_agent;
-        f->call_base = calls;
         return true;
     }
     int update_model_dev(int, const float *, const float *, const float *, float *loss, hipStream_t) override {
@@ -132,6 +136,12 @@ struct azd_engine {
     bool barrier_step = false;
     azd::PersistArgs *d_pargs = nullptr;
     azd::PersistArgs *h_pargs = nullptr; // pinned
+    azd::PersistArgs pargs_sent{};       // what d_pargs holds: the block is re-sent only when it changed
+    bool pargs_valid = false;
+    bool log_clean = false;              // d_log_key is all ones (k_argmin_log1 leaves it so; the barrier step and an abort do not)
+    bool pool_clean = false;             // PoolCtl, the queue slots and the join counters are zero (a completed pool launch leaves them so)
+    bool pool_failed = false;            // a pool launch aborted: this engine takes the asynchronous step from then on
+    uint32_t *d_resume = nullptr;        // [B] take-over of an aborted pool launch by k_async (StepLaunch::resume)
     unsigned long long *d_log_key = nullptr;
     uint32_t *d_log_node = nullptr;
     int log_calls = 0;
@@ -208,11 +218,14 @@ int next_pow2(int v) {
     return p;
 }
 
-int sync_status(azd_engine *e) {
+int fetch_status(azd_engine *e) { // the device's status block -> e->h_status, behind everything queued on the stream
     AZD_HIP(hipMemcpyAsync(e->h_status, e->a.status, sizeof(StatusRec), hipMemcpyDeviceToHost, e->stream));
     AZD_HIP(hipStreamSynchronize(e->stream));
     e->time_collect();
     AZD_HIP(hipGetLastError());
+    return AZD_OK;
+}
+int check_status(azd_engine *e) {
     if (e->h_status->failed != 0) {
         // distinguish capacity from unreachable by reading the flags
         std::vector<uint32_t> fl((size_t)e->a.B);
@@ -225,6 +238,10 @@ int sync_status(azd_engine *e) {
         return (all & (FLAG_UNREACHABLE | FLAG_LOOP_GUARD)) ? AZD_ERR_UNREACHABLE : AZD_ERR_CAPACITY;
     }
     return AZD_OK;
+}
+int sync_status(azd_engine *e) {
+    const int st = fetch_status(e);
+    return st ? st : check_status(e);
 }
 
 // dense-graph space: check the roots and hand the device what it works with -- the modifiable slots ranked by ACTION ID
@@ -509,6 +526,7 @@ int azd_evaluator_update_model_dev(azd_evaluator *ev, int batch, const float *d_
     AZD_HIP(hipSetDevice(ev->device));
     return ev->update_model_dev(batch, d_states, d_observations, d_action_weights, loss, (hipStream_t)stream);
 }
+int azd_debug_hash_stream_via_evaluators(azd_evaluator *ev, int on) { return ev ? ev->debug_serve_from_pool(on) : AZD_ERR_INVALID_ARGUMENT; }
 int azd_evaluator_set_weight_storage(azd_evaluator *ev, int dtype) { return ev ? ev->set_weight_storage(dtype) : AZD_ERR_INVALID_ARGUMENT; }
 int64_t azd_evaluator_num_params(azd_evaluator *ev) { return ev ? ev->num_params() : 0; }
 int azd_evaluator_get_params(azd_evaluator *ev, float *out) { return ev && out ? ev->get_params(out) : AZD_ERR_INVALID_ARGUMENT; }
@@ -689,6 +707,8 @@ int azd_engine_create(azd_engine **out, const azd_engine_config *cfg, azd_evalua
         TRY(e->alloc(&e->pool.join, B));
         TRY(e->alloc(&e->pool.pend, B));
         TRY(e->alloc(&e->pool.stamp, B));
+        TRY(e->alloc(&e->pool.post_call, B));
+        TRY(e->alloc(&e->d_resume, B));
     }
     e->log_calls = 1024;
     {
@@ -829,9 +849,9 @@ int azd_engine_par_roll_out_episodes(azd_engine *e, const uint32_t *tol, int n_t
     const char *why_a = "", *why_b = "";
     const char *why_p = "";
     azd::PoolArgs pool = e->pool;
-    const bool use_pool = fusable && e->pool_step && azd::pool_plan(e->a, fe, &pool, &dyn_stride, &dyn_bytes, &why_p);
-    const bool use_async = fusable && !use_pool && !e->barrier_step && azd::async_plan(e->a, fe, &dyn_stride, &dyn_bytes, &why_a);
-    const bool use_barrier = fusable && !use_pool && !use_async && azd::persist_plan(e->a, fe, &dyn_stride, &dyn_bytes, &why_b);
+    bool use_pool = fusable && e->pool_step && azd::pool_plan(e->a, fe, &pool, &dyn_stride, &dyn_bytes, &why_p);
+    bool use_async = fusable && !use_pool && !e->barrier_step && azd::async_plan(e->a, fe, &dyn_stride, &dyn_bytes, &why_a);
+    bool use_barrier = fusable && !use_pool && !use_async && azd::persist_plan(e->a, fe, &dyn_stride, &dyn_bytes, &why_b);
     // which form runs is part of the result a caller may want to check (azd_engine_step_form): the launch-per-phase
     // form is several times slower than the CU-resident ones
     e->step_form = use_pool ? AZD_STEP_POOL : use_async ? AZD_STEP_ASYNC : use_barrier ? AZD_STEP_BARRIER : AZD_STEP_PER_CALL;
@@ -844,15 +864,20 @@ int azd_engine_par_roll_out_episodes(azd_engine *e, const uint32_t *tol, int n_t
         else e->step_reason += why_a;
         if (fusable && !use_barrier && *why_b) e->step_reason += std::string("; ") + why_b;
     }
+    if (e->pool_failed && use_async)
+        e->step_reason = "an earlier pool launch of this engine aborted (a queue wait ran into its bound): asynchronous step";
     int pool_blocks = 0;
+    bool status_fresh = false; // h_status already holds the status behind the last launch
     if (use_pool) {
         // Split of the CUs between the two roles, in proportion to the CU time a row costs an evaluator and a call costs
         // the searchers.  AZD_POOL_EVAL_WGS / AZD_POOL_SEARCH_WGS override (experiments).
         const int B = e->a.B;
         int n_eval = 0;
-        if (fe.kind == 3) {
+        if (fe.kind >= 3) {
             double flop = 0;
-            for (int l = 0; l < fe.n_layers; ++l) flop += 2.0 * fe.dims[l] * fe.dims[l + 1];
+            if (fe.kind == 3)
+                for (int l = 0; l < fe.n_layers; ++l) flop += 2.0 * fe.dims[l] * fe.dims[l + 1];
+            else flop = 2.0 * 256.0 * (e->a.S + 512.0 + e->a.A); // hashed rows (test harness): the split a 3 x 256 model would get
             // measured (profiles/r02_pool_probe.txt): a 16-row fp32 batch of the 3 x 256 MLP takes 25 us of an evaluator
             // CU, bf16 storage 16 us; pure search 4.65 us of a CU per call on young trees.  Whole epochs (older, larger
             // trees) want a few more evaluators than that ratio says: best 88-100 of 256 at 4096 agents fp32, 80 at 8192,
@@ -884,6 +909,24 @@ int azd_engine_par_roll_out_episodes(azd_engine *e, const uint32_t *tol, int n_t
         n_search = n_search > want ? want : n_search;
         n_search = n_search < 1 ? 1 : n_search;
         if (const char *env = getenv("AZD_POOL_SEARCH_WGS")) n_search = atoi(env) > 0 ? atoi(env) : n_search;
+        // Searcher and evaluator workgroups spin-wait on each other: every one of them must be RESIDENT, whatever the overrides
+        // above ask for and whatever the device can hold (a CU mask, a partition, another kernel's LDS).  Clamp the grid to the
+        // co-resident capacity the runtime reports, evaluators first (they are dispatched first: a grid of evaluators alone
+        // would never let a searcher in); with no room for one of each the call takes the asynchronous step instead.
+        int capacity = azd::pool_max_resident(e->a, dyn_bytes, e->n_cus);
+        if (const char *env = getenv("AZD_POOL_MAX_RESIDENT")) capacity = atoi(env); // tests: a device that holds fewer workgroups
+        if (fe.kind < 3) n_eval = 0; // TrivialModel / in-wave hash stream: nothing to serve
+        if (n_eval + n_search > capacity) {
+            if (n_eval > capacity / 2) n_eval = capacity / 2;
+            if (fe.kind >= 3 && n_eval < 1) n_eval = 1;
+            n_search = capacity - n_eval;
+        }
+        if (n_search < 1 || capacity < 1) {
+            use_pool = false;
+            char buf[160];
+            snprintf(buf, sizeof(buf), "pool step: the device holds %d of its workgroups at once; it needs an evaluator and a searcher resident together; ", capacity);
+            e->step_reason = buf;
+        }
         pool.n_eval = n_eval;
         // With more agents than searching waves an agent's cycle is mostly waiting for a wave (92 of 179 us at 8192 agents);
         // in lane mode the agents behind the mean progress are taken first, so that the slow chains do not also queue.
@@ -899,45 +942,117 @@ int azd_engine_par_roll_out_episodes(azd_engine *e, const uint32_t *tol, int n_t
         // launch, when the slowest chains are all that is left.
         pool.early_post = (double)B <= 1.25 * n_search * 16 ? 1 : 2; // 16 waves per searcher workgroup
         if (const char *env = getenv("AZD_POOL_EARLY_POST")) pool.early_post = atoi(env);
+        pool.debug_abort_call = 0;
+        if (const char *env = getenv("AZD_POOL_DEBUG_ABORT_CALL")) pool.debug_abort_call = (uint32_t)atoi(env);
         pool_blocks = n_eval + n_search;
         e->pool_eval_wgs = n_eval;
         e->pool_search_wgs = n_search;
     }
+    if (e->pool_step && fusable && !use_pool) { // the pool step was wanted and cannot run: the next form down
+        use_async = !e->barrier_step && azd::async_plan(e->a, fe, &dyn_stride, &dyn_bytes, &why_a);
+        use_barrier = !use_async && azd::persist_plan(e->a, fe, &dyn_stride, &dyn_bytes, &why_b);
+        if (!use_async) e->step_reason += why_a;
+        if (!use_async && !use_barrier && *why_b) e->step_reason += std::string("; ") + why_b;
+    }
+    e->step_form = use_pool ? AZD_STEP_POOL : use_async ? AZD_STEP_ASYNC : use_barrier ? AZD_STEP_BARRIER : AZD_STEP_PER_CALL;
     if (use_pool || use_async || use_barrier) {
-        // CU-resident forms: the whole call chain, n_calls times, in one launch per <= log_calls calls
+        // CU-resident forms: the whole call chain, n_calls times, in one launch per <= log_calls calls.  What a launch costs
+        // the host: the argument block is re-sent only when it changed (per-launch values are kernel arguments), the log and
+        // the pool's control block are left clean by k_argmin_log1, the abort flag comes back with the status block.
+        auto send_args = [&](const azd::PoolArgs &pl) -> int {
+            azd::PersistArgs &pa = e->pargs_sent;
+            azd::PersistArgs now;
+            memset(&now, 0, sizeof(now)); // (padding bytes compare equal)
+            now.a = e->a;
+            now.tol = t;
+            now.ev = fe;
+            now.pool = pl;
+            if (e->pargs_valid && memcmp(&pa, &now, sizeof(now)) == 0) return AZD_OK;
+            AZD_HIP(hipStreamSynchronize(e->stream)); // the pinned block may still be in flight from the copy before
+            memcpy(e->h_pargs, &now, sizeof(now));
+            AZD_HIP(hipMemcpyAsync(e->d_pargs, e->h_pargs, sizeof(azd::PersistArgs), hipMemcpyHostToDevice, e->stream));
+            memcpy(&pa, &now, sizeof(now));
+            e->pargs_valid = true;
+            return AZD_OK;
+        };
+        auto clear_pool = [&]() -> int { // empty queues, nobody claimed, no call done
+            AZD_HIP(hipMemsetAsync(pool.ctl, 0, sizeof(azd::PoolCtl), e->stream));
+            AZD_HIP(hipMemsetAsync(pool.ready_slots, 0, e->pool_slot_words * sizeof(uint32_t), e->stream));
+            AZD_HIP(hipMemsetAsync(pool.join, 0, (size_t)e->a.B * sizeof(uint32_t), e->stream));
+            e->pool_clean = true;
+            return AZD_OK;
+        };
         int left = n_calls;
         while (left > 0) {
             const int k = left < e->log_calls ? left : e->log_calls;
-            e->ev->fused_desc(&fe); // refresh call_base
-            // the pinned block may still be in flight from the previous launch's copy
-            AZD_HIP(hipStreamSynchronize(e->stream));
-            e->h_pargs->a = e->a;
-            e->h_pargs->tol = t;
-            e->h_pargs->ev = fe;
-            e->h_pargs->pool = pool;
-            AZD_HIP(hipMemcpyAsync(e->d_pargs, e->h_pargs, sizeof(azd::PersistArgs), hipMemcpyHostToDevice, e->stream));
-            if (use_pool) { // empty queues, nobody claimed, no call done
-                AZD_HIP(hipMemsetAsync(pool.ctl, 0, sizeof(azd::PoolCtl), e->stream));
-                AZD_HIP(hipMemsetAsync(pool.ready_slots, 0, e->pool_slot_words * sizeof(uint32_t), e->stream));
-                AZD_HIP(hipMemsetAsync(pool.join, 0, (size_t)e->a.B * sizeof(uint32_t), e->stream));
+            status_fresh = false;
+            st = send_args(pool);
+            if (st) return st;
+            if (use_pool && !e->pool_clean) {
+                st = clear_pool();
+                if (st) return st;
             }
+            if (!use_barrier && !e->log_clean) {
+                AZD_HIP(hipMemsetAsync(e->d_log_key, 0xFF, (size_t)e->log_calls * sizeof(unsigned long long), e->stream));
+                e->log_clean = true;
+            }
+            azd::StepLaunch sl;
+            sl.n_calls = k;
+            sl.call_base = e->ev->calls;
+            sl.log_key = e->d_log_key;
+            sl.resume = nullptr;
+            sl.ctl = use_pool ? pool.ctl : nullptr;
             e->time_begin(0);
-            if (use_pool) azd::launch_pool(e->a, e->d_pargs, k, e->d_log_key, fe.params, fe.wpk, pool_blocks, dyn_stride, dyn_bytes, e->stream);
-            else if (use_async) azd::launch_async(e->a, e->d_pargs, k, e->d_log_key, fe.params, fe.wpk, dyn_stride, dyn_bytes, e->stream);
-            else azd::launch_persist(e->a, e->d_pargs, k, e->d_log_key, e->d_log_node, dyn_stride, dyn_bytes, e->stream);
+            if (use_pool) azd::launch_pool(e->a, e->d_pargs, sl, fe.params, fe.wpk, pool_blocks, dyn_stride, dyn_bytes, e->stream);
+            else if (use_async) azd::launch_async(e->a, e->d_pargs, sl, fe.params, fe.wpk, dyn_stride, dyn_bytes, e->stream);
+            else {
+                azd::launch_persist(e->a, e->d_pargs, sl, e->d_log_node, dyn_stride, dyn_bytes, e->stream);
+                e->log_clean = false;
+            }
             e->time_end();
-            e->ev->calls += (uint64_t)k;
             left -= k;
-            if (use_pool) { // a wait that ran into its bound ends the launch instead of hanging it: report, do not go on
-                uint32_t ab = 0;
-                AZD_HIP(hipMemcpyAsync(&ab, &pool.ctl->abort, sizeof(ab), hipMemcpyDeviceToHost, e->stream));
-                AZD_HIP(hipStreamSynchronize(e->stream));
-                if (ab) {
-                    e->time_collect();
-                    azd::g_last_error = "pool step: a queue wait ran into its bound (no evaluator or searcher workgroup made progress)";
-                    return AZD_ERR_UNREACHABLE;
+            if (use_pool) {
+                // A wait that ran into its bound ends a pool launch instead of hanging it (PoolCtl::abort; k_argmin_log1 has put
+                // the flag into the status block and left the log alone).  The trees are consistent -- a wave never leaves an
+                // agent inside a call -- so the asynchronous step, whose workgroups need no company, takes the launch over
+                // where every agent stands, and this engine stays with it.
+                st = fetch_status(e);
+                if (st) return st;
+                status_fresh = left == 0; // the last launch's status is in, and nothing ran behind it
+                if (e->h_status->pool_abort) {
+                    e->pool_clean = false;
+                    e->log_clean = false; // (it holds the aborted launch's candidates, which the take-over's replay needs: not cleared here)
+                    e->pool_failed = true;
+                    e->pool_step = false;
+                    uint32_t as = 0;
+                    size_t ab = 0;
+                    const char *why_t = "";
+                    if (!azd::async_plan(e->a, fe, &as, &ab, &why_t)) {
+                        e->time_collect();
+                        azd::g_last_error = std::string("pool step: a queue wait ran into its bound, and the asynchronous step cannot take over: ") + why_t;
+                        return AZD_ERR_UNREACHABLE;
+                    }
+                    azd::launch_pool_resume_scan(e->a, pool, k, e->d_resume, e->stream);
+                    st = clear_pool();
+                    if (st) return st;
+                    e->pool_clean = true;
+                    sl.resume = e->d_resume;
+                    sl.ctl = nullptr;
+                    e->time_begin(0);
+                    azd::launch_async(e->a, e->d_pargs, sl, fe.params, fe.wpk, as, ab, e->stream);
+                    e->time_end();
+                    e->log_clean = true; // k_argmin_log1 has replayed and cleared it
+                    status_fresh = false;
+                    e->step_form = AZD_STEP_ASYNC;
+                    e->step_reason = "pool step aborted (a queue wait ran into its bound: no evaluator or searcher workgroup made progress); "
+                                     "the asynchronous step took the launch over and serves this engine from here on";
+                    use_pool = false;
+                    use_async = true;
+                    dyn_stride = as;
+                    dyn_bytes = ab;
                 }
             }
+            e->ev->calls += (uint64_t)k;
         }
         AZD_HIP(hipGetLastError());
     } else {
@@ -985,7 +1100,7 @@ int azd_engine_par_roll_out_episodes(azd_engine *e, const uint32_t *tol, int n_t
                 azd::launch_argmin(e->a, 0, e->stream); // :190
             }
     }
-    st = sync_status(e);
+    st = status_fresh ? check_status(e) : sync_status(e);
     if (improved) *improved = (int)(e->h_status->improved - e->seen_improved);
     e->seen_improved = e->h_status->improved;
     return st;

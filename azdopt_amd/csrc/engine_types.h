@@ -104,7 +104,7 @@ struct StatusRec { // small device block copied back after every host-visible ca
     unsigned long long improved;   // k_argmin calls that improved the argmin
     unsigned long long expansions; // sum over agents and calls (metric numerator)
     unsigned long long failed;     // agents with a non-zero flag
-    unsigned long long pad;
+    unsigned long long pool_abort; // the pool launch before this read-back ended on PoolCtl::abort (k_argmin_log1 copies the flag here)
 };
 
 struct Arenas {
@@ -167,8 +167,10 @@ struct Arenas {
 
 // what the persistent step needs to run the evaluator inside the kernel
 struct FusedEval {
-    int kind;                // 0 not fusable (external), 1 TrivialModel, 2 hash stream, 3 MLP
-    uint64_t seed, first_agent, call_base; // hash stream
+    int kind;                // 0 not fusable (external), 1 TrivialModel, 2 hash stream, 3 MLP,
+                             // 4 hash stream served by the pool step's EVALUATOR workgroups (test harness: the rows of the fixed
+                             // prediction stream take the MLP's way through the queues, so the oracle can check whole launches)
+    uint64_t seed, first_agent; // hash stream (the index of a launch's first call is a kernel argument: StepLaunch::call_base)
     const float *params;     // MLP: flat parameters (per layer W[out][in] then b[out])
     int n_layers;
     int dims[8];
@@ -242,6 +244,20 @@ struct PoolArgs {
     uint32_t eval_stride;  // floats per row of an evaluator batch in LDS
     uint32_t eval_out_off; // offset (floats) of the head's output inside a row
     uint32_t eval_rows;    // rows an evaluator batch may hold: 16, or 32 (two MFMA row tiles per weight fragment)
+    uint32_t *post_call;   // [B] FusedEval::kind 4 only: the call whose row the agent has posted (the evaluator hashes it)
+    uint32_t debug_abort_call; // test hook (AZD_POOL_DEBUG_ABORT_CALL): agent 0 raises PoolCtl::abort when it has completed this many calls; 0: off
+};
+
+// Per-launch values of the CU-resident step forms.  They travel as KERNEL ARGUMENTS, so that the argument block in device
+// memory (PersistArgs) stays what it was from launch to launch and is re-sent only when something in it changed.
+struct StepLaunch {
+    int n_calls;
+    unsigned long long call_base;  // hash stream: index of the launch's first call (FusedEval kind 2 / 4)
+    unsigned long long *log_key;   // [>= n_calls] per-call argmin candidates, all ones when the launch starts (k_argmin_log1 leaves them so)
+    // k_async taking over from an aborted pool launch (engine.hip): [B] calls the agent has completed | 1u << 31 if its last
+    // call ended on a new node whose prediction row / add_actions are still due.  Null: every agent starts at call 0.
+    const uint32_t *resume;
+    PoolCtl *ctl;                  // pool step: the control block k_argmin_log1 reports the abort flag from and clears; else null
 };
 
 struct PersistArgs { // argument block of the persistent step, read from device memory
@@ -259,15 +275,21 @@ void launch_rollout(const Arenas &a, const TolTable &tol, void *stream);
 void launch_argmin(const Arenas &a, int init_mode, void *stream);
 void launch_observe(const Arenas &a, uint32_t n_obs_tol, void *stream);
 bool async_plan(const Arenas &a, const FusedEval &ev, uint32_t *dyn_stride, size_t *dyn_bytes, const char **why = nullptr);
-void launch_async(const Arenas &a, const PersistArgs *d_args, int n_calls, unsigned long long *log_key,
+void launch_async(const Arenas &a, const PersistArgs *d_args, const StepLaunch &sl,
                   const float *params, const void *wpk, uint32_t dyn_stride, size_t dyn_bytes, void *stream);
 bool persist_plan(const Arenas &a, const FusedEval &ev, uint32_t *dyn_stride, size_t *dyn_bytes, const char **why = nullptr);
 // pool step (pool_kernels.hip / ramsey_pool_kernels.hip): the plan also lays out an evaluator batch (pool->eval_*)
 bool pool_plan(const Arenas &a, const FusedEval &ev, PoolArgs *pool, uint32_t *dyn_stride, size_t *dyn_bytes, const char **why = nullptr);
-void launch_pool(const Arenas &a, const PersistArgs *d_args, int n_calls, unsigned long long *log_key, const float *params,
+void launch_pool(const Arenas &a, const PersistArgs *d_args, const StepLaunch &sl, const float *params,
                  const void *wpk, int n_blocks, uint32_t dyn_stride, size_t dyn_bytes, void *stream);
+// workgroups of k_pool the device can hold at once with this much dynamic LDS (occupancy query x CUs): the pool step's
+// searcher and evaluator workgroups spin-wait on each other, so all of them must be resident together
+int pool_max_resident(const Arenas &a, size_t dyn_bytes, int n_cus);
+int ramsey_pool_max_resident(const Arenas &a, size_t dyn_bytes, int n_cus);
+// after an aborted pool launch: resume[t] for k_async (StepLaunch::resume) from the trees and PoolArgs::pend
+void launch_pool_resume_scan(const Arenas &a, const PoolArgs &pool, int n_calls, uint32_t *resume, void *stream);
 bool ramsey_pool_plan(const Arenas &a, const FusedEval &ev, PoolArgs *pool, uint32_t *dyn_stride, size_t *dyn_bytes, const char **why = nullptr);
-void ramsey_launch_pool(const Arenas &a, const PersistArgs *d_args, int n_calls, unsigned long long *log_key, const float *params,
+void ramsey_launch_pool(const Arenas &a, const PersistArgs *d_args, const StepLaunch &sl, const float *params,
                         const void *wpk, int n_blocks, uint32_t dyn_stride, size_t dyn_bytes, void *stream);
 void launch_probe_xcc(uint32_t *d_out, int n_blocks, void *stream); // HW_REG_XCC_ID of every block of a launch (tests)
 
@@ -278,7 +300,7 @@ void dense_launch_add_actions(const Arenas &a, int root_mode, void *stream);
 void dense_launch_rollout(const Arenas &a, const TolTable &tol, void *stream);
 void dense_launch_argmin(const Arenas &a, int init_mode, void *stream);
 void dense_launch_observe(const Arenas &a, uint32_t n_obs_tol, void *stream);
-void launch_persist(const Arenas &a, const PersistArgs *d_args, int n_calls, unsigned long long *log_key,
+void launch_persist(const Arenas &a, const PersistArgs *d_args, const StepLaunch &sl,
                     uint32_t *log_node, uint32_t dyn_stride, size_t dyn_bytes, void *stream);
 void launch_c21_modify_roots(const Arenas &a, uint64_t seed, uint64_t epoch, uint64_t first_agent, int kmin, int kmax,
                              uint8_t *d_parents, uint64_t *d_perm, void *stream);
@@ -297,10 +319,10 @@ void ramsey_launch_observe(const Arenas &a, uint32_t n_obs_tol, void *stream);
 void ramsey_launch_modify_roots(const Arenas &a, uint64_t seed, uint64_t epoch, uint64_t first_agent, int kmin, int kmax,
                                 uint8_t *d_colors, uint64_t *d_perm, void *stream);
 bool ramsey_async_plan(const Arenas &a, const FusedEval &ev, uint32_t *dyn_stride, size_t *dyn_bytes, const char **why = nullptr);
-void ramsey_launch_async(const Arenas &a, const PersistArgs *d_args, int n_calls, unsigned long long *log_key,
+void ramsey_launch_async(const Arenas &a, const PersistArgs *d_args, const StepLaunch &sl,
                          const float *params, const void *wpk, uint32_t dyn_stride, size_t dyn_bytes, void *stream);
 bool ramsey_persist_plan(const Arenas &a, const FusedEval &ev, uint32_t *dyn_stride, size_t *dyn_bytes, const char **why = nullptr);
-void ramsey_launch_persist(const Arenas &a, const PersistArgs *d_args, int n_calls, unsigned long long *log_key,
+void ramsey_launch_persist(const Arenas &a, const PersistArgs *d_args, const StepLaunch &sl,
                            uint32_t *log_node, uint32_t dyn_stride, size_t dyn_bytes, void *stream);
 
 } // namespace azd

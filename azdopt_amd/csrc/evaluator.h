@@ -47,6 +47,7 @@ struct azd_evaluator {
     virtual int get_params(float *) { return AZD_ERR_UNSUPPORTED; }
     virtual int set_params(const float *) { return AZD_ERR_UNSUPPORTED; }
     virtual int set_weight_storage(int) { return AZD_ERR_UNSUPPORTED; }
+    virtual int debug_serve_from_pool(int) { return AZD_ERR_UNSUPPORTED; } // hash stream only (azd_debug_hash_stream_via_evaluators)
     int ensure_staging(int batch);
 };
 

@@ -25,20 +25,19 @@ namespace azd {
     }
 
 template <class SP>
-static void l_async(const Arenas &a, const PersistArgs *d_args, int n_calls, unsigned long long *log_key,
+static void l_async(const Arenas &a, const PersistArgs *d_args, const StepLaunch &sl,
                     const float *params, const void *wpk, uint32_t dyn_stride, size_t dyn_bytes, hipStream_t st) {
     // dynamic LDS beyond the default 64 KB needs the attribute, which is per DEVICE (the current one): set on every
     // launch -- a host-side call, once per <= 1024 search calls -- so that engines on several devices in one process
     // all get it; the plans have already checked that the request fits beside the kernel's static LDS
     if (hipFuncSetAttribute((const void *)k_async<SP>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn_bytes) != hipSuccess) return; // sticky: the caller's hipGetLastError reports it
     const int n_wg = (a.B + PERSIST_WAVES - 1) / PERSIST_WAVES;
-    (void)hipMemsetAsync(log_key, 0xFF, (size_t)n_calls * sizeof(unsigned long long), st);
-    k_async<SP><<<dim3(n_wg), dim3(PERSIST_WAVES * 64), dyn_bytes, st>>>(d_args, n_calls, log_key, dyn_stride, params, a.state_vecs, a.h_theta, wpk);
-    k_argmin_log1<SP><<<dim3(1), dim3(64), SP::dyn_bytes(a), st>>>(a, n_calls, log_key);
+    k_async<SP><<<dim3(n_wg), dim3(PERSIST_WAVES * 64), dyn_bytes, st>>>(d_args, sl.n_calls, sl.log_key, dyn_stride, params, a.state_vecs, a.h_theta, wpk, sl.call_base, sl.resume);
+    k_argmin_log1<SP><<<dim3(1), dim3(64), SP::dyn_bytes(a), st>>>(a, sl.n_calls, sl.log_key, nullptr);
 }
-void ramsey_launch_async(const Arenas &a, const PersistArgs *d_args, int n_calls, unsigned long long *log_key,
+void ramsey_launch_async(const Arenas &a, const PersistArgs *d_args, const StepLaunch &sl,
                          const float *params, const void *wpk, uint32_t dyn_stride, size_t dyn_bytes, void *stream) {
-    DISPATCH_RKW(a, l_async, a, d_args, n_calls, log_key, params, wpk, dyn_stride, dyn_bytes, (hipStream_t)stream);
+    DISPATCH_RKW(a, l_async, a, d_args, sl, params, wpk, dyn_stride, dyn_bytes, (hipStream_t)stream);
 }
 // LDS plan of the asynchronous step: the per-wave region holds the search scratch + the clique counts
 // during a call, and the row's activations [x][h0][h1] while the agent waits

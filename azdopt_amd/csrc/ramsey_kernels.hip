@@ -45,15 +45,15 @@ static void l_observe(const Arenas &a, uint32_t tol, hipStream_t st) {
     k_observe<SP><<<dim3(a.B), dim3(64), SP::dyn_bytes(a), st>>>(a, tol);
 }
 template <class SP>
-static void l_persist(const Arenas &a, const PersistArgs *d_args, int n_calls, unsigned long long *log_key,
+static void l_persist(const Arenas &a, const PersistArgs *d_args, const StepLaunch &sl,
                       uint32_t *log_node, uint32_t dyn_stride, size_t dyn_bytes, hipStream_t st) {
     // dynamic LDS beyond the default 64 KB needs the attribute, which is per DEVICE (the current one): set on every
     // launch -- a host-side call, once per <= 1024 search calls -- so that engines on several devices in one process
     // all get it; the plans have already checked that the request fits beside the kernel's static LDS
     if (hipFuncSetAttribute((const void *)k_persist<SP>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn_bytes) != hipSuccess) return; // sticky: the caller's hipGetLastError reports it
     const int n_wg = (a.B + PERSIST_WAVES - 1) / PERSIST_WAVES;
-    k_persist<SP><<<dim3(n_wg), dim3(PERSIST_WAVES * 64), dyn_bytes, st>>>(d_args, n_calls, log_key, log_node, dyn_stride);
-    k_argmin_log<SP><<<dim3(1), dim3(64), SP::dyn_bytes(a), st>>>(a, n_calls, n_wg, log_key, log_node);
+    k_persist<SP><<<dim3(n_wg), dim3(PERSIST_WAVES * 64), dyn_bytes, st>>>(d_args, sl.n_calls, sl.log_key, log_node, dyn_stride, sl.call_base);
+    k_argmin_log<SP><<<dim3(1), dim3(64), SP::dyn_bytes(a), st>>>(a, sl.n_calls, n_wg, sl.log_key, log_node);
 }
 
 template <class SP>
@@ -110,9 +110,9 @@ bool ramsey_persist_plan(const Arenas &a, const FusedEval &ev, uint32_t *dyn_str
     *dyn_bytes = total;
     return true;
 }
-void ramsey_launch_persist(const Arenas &a, const PersistArgs *d_args, int n_calls, unsigned long long *log_key,
+void ramsey_launch_persist(const Arenas &a, const PersistArgs *d_args, const StepLaunch &sl,
                            uint32_t *log_node, uint32_t dyn_stride, size_t dyn_bytes, void *stream) {
-    DISPATCH_RKW(a, l_persist, a, d_args, n_calls, log_key, log_node, dyn_stride, dyn_bytes, (hipStream_t)stream);
+    DISPATCH_RKW(a, l_persist, a, d_args, sl, log_node, dyn_stride, dyn_bytes, (hipStream_t)stream);
 }
 
 } // namespace azd

@@ -25,16 +25,30 @@ namespace azd {
     }
 
 template <class SP>
-static void l_pool(const Arenas &a, const PersistArgs *d_args, int n_calls, unsigned long long *log_key, const float *params,
+static void l_pool(const Arenas &a, const PersistArgs *d_args, const StepLaunch &sl, const float *params,
                    const void *wpk, int n_blocks, uint32_t dyn_stride, size_t dyn_bytes, hipStream_t st) {
     if (hipFuncSetAttribute((const void *)k_pool<SP>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn_bytes) != hipSuccess) return;
-    (void)hipMemsetAsync(log_key, 0xFF, (size_t)n_calls * sizeof(unsigned long long), st);
-    k_pool<SP><<<dim3(n_blocks), dim3(PERSIST_WAVES * 64), dyn_bytes, st>>>(d_args, n_calls, log_key, dyn_stride, params, a.state_vecs, a.h_theta, wpk);
-    k_argmin_log1<SP><<<dim3(1), dim3(64), SP::dyn_bytes(a), st>>>(a, n_calls, log_key);
+    k_pool<SP><<<dim3(n_blocks), dim3(PERSIST_WAVES * 64), dyn_bytes, st>>>(d_args, sl.n_calls, sl.log_key, dyn_stride, params, a.state_vecs, a.h_theta, wpk, sl.call_base);
+    k_argmin_log1<SP><<<dim3(1), dim3(64), SP::dyn_bytes(a), st>>>(a, sl.n_calls, sl.log_key, sl.ctl);
 }
-void ramsey_launch_pool(const Arenas &a, const PersistArgs *d_args, int n_calls, unsigned long long *log_key, const float *params,
+void ramsey_launch_pool(const Arenas &a, const PersistArgs *d_args, const StepLaunch &sl, const float *params,
                         const void *wpk, int n_blocks, uint32_t dyn_stride, size_t dyn_bytes, void *stream) {
-    DISPATCH_RKW(a, l_pool, a, d_args, n_calls, log_key, params, wpk, n_blocks, dyn_stride, dyn_bytes, (hipStream_t)stream);
+    DISPATCH_RKW(a, l_pool, a, d_args, sl, params, wpk, n_blocks, dyn_stride, dyn_bytes, (hipStream_t)stream);
+}
+template <class SP>
+static void q_pool_resident(int *out, size_t dyn_bytes) {
+    int nb = 0;
+    if (hipFuncSetAttribute((const void *)k_pool<SP>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn_bytes) != hipSuccess ||
+        hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, (const void *)k_pool<SP>, PERSIST_WAVES * 64, dyn_bytes) != hipSuccess) {
+        (void)hipGetLastError();
+        nb = 0;
+    }
+    *out = nb;
+}
+int ramsey_pool_max_resident(const Arenas &a, size_t dyn_bytes, int n_cus) {
+    int nb = 0;
+    DISPATCH_RKW(a, q_pool_resident, &nb, dyn_bytes);
+    return nb * n_cus;
 }
 bool ramsey_pool_plan(const Arenas &a, const FusedEval &ev, PoolArgs *pool, uint32_t *dyn_stride, size_t *dyn_bytes, const char **why) {
     const char *dummy;

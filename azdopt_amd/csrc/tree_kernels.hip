@@ -40,18 +40,53 @@ __global__ void k_hash_predictions(float *out, int batch, int action_dim, uint64
 #include "async_step.inc"
 #include "pool_step.inc"
 template <class SP>
-static void l_pool(const Arenas &a, const PersistArgs *d_args, int n_calls, unsigned long long *log_key, const float *params,
+static void l_pool(const Arenas &a, const PersistArgs *d_args, const StepLaunch &sl, const float *params,
                    const void *wpk, int n_blocks, uint32_t dyn_stride, size_t dyn_bytes, hipStream_t st) {
     // the dynamic-LDS attribute is per device: set on every launch (see l_async)
     if (hipFuncSetAttribute((const void *)k_pool<SP>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn_bytes) != hipSuccess) return;
-    (void)hipMemsetAsync(log_key, 0xFF, (size_t)n_calls * sizeof(unsigned long long), st);
-    k_pool<SP><<<dim3(n_blocks), dim3(PERSIST_WAVES * 64), dyn_bytes, st>>>(d_args, n_calls, log_key, dyn_stride, params, a.state_vecs, a.h_theta, wpk);
-    k_argmin_log1<SP><<<dim3(1), dim3(64), SP::dyn_bytes(a), st>>>(a, n_calls, log_key);
+    k_pool<SP><<<dim3(n_blocks), dim3(PERSIST_WAVES * 64), dyn_bytes, st>>>(d_args, sl.n_calls, sl.log_key, dyn_stride, params, a.state_vecs, a.h_theta, wpk, sl.call_base);
+    k_argmin_log1<SP><<<dim3(1), dim3(64), SP::dyn_bytes(a), st>>>(a, sl.n_calls, sl.log_key, sl.ctl);
 }
-void launch_pool(const Arenas &a, const PersistArgs *d_args, int n_calls, unsigned long long *log_key, const float *params,
+void launch_pool(const Arenas &a, const PersistArgs *d_args, const StepLaunch &sl, const float *params,
                  const void *wpk, int n_blocks, uint32_t dyn_stride, size_t dyn_bytes, void *stream) {
-    if (a.space == SPACE_RAMSEY) return ramsey_launch_pool(a, d_args, n_calls, log_key, params, wpk, n_blocks, dyn_stride, dyn_bytes, stream);
-    DISPATCH_KW(a, l_pool, a, d_args, n_calls, log_key, params, wpk, n_blocks, dyn_stride, dyn_bytes, (hipStream_t)stream);
+    if (a.space == SPACE_RAMSEY) return ramsey_launch_pool(a, d_args, sl, params, wpk, n_blocks, dyn_stride, dyn_bytes, stream);
+    DISPATCH_KW(a, l_pool, a, d_args, sl, params, wpk, n_blocks, dyn_stride, dyn_bytes, (hipStream_t)stream);
+}
+template <class SP>
+static void q_pool_resident(int *out, size_t dyn_bytes) {
+    int nb = 0;
+    if (hipFuncSetAttribute((const void *)k_pool<SP>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn_bytes) != hipSuccess ||
+        hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, (const void *)k_pool<SP>, PERSIST_WAVES * 64, dyn_bytes) != hipSuccess) {
+        (void)hipGetLastError();
+        nb = 0;
+    }
+    *out = nb;
+}
+int pool_max_resident(const Arenas &a, size_t dyn_bytes, int n_cus) {
+    if (a.space == SPACE_RAMSEY) return ramsey_pool_max_resident(a, dyn_bytes, n_cus);
+    int nb = 0;
+    DISPATCH_KW(a, q_pool_resident, &nb, dyn_bytes);
+    return nb * n_cus;
+}
+// After an aborted pool launch (PoolCtl::abort: a wait ran into its bound): where every agent stands, for the asynchronous
+// step that takes over (StepLaunch::resume).  A wave never leaves an agent inside a call, so an agent is in one of three
+// states: never taken (index >= claimed: no call made), waiting for the prediction row of its last call's new node (the node
+// it stands on has no actions yet; PendRec::call = calls completed), or through all its calls.
+__global__ void k_pool_resume_scan(Arenas a, const PendRec *__restrict__ pend, const uint32_t *__restrict__ claim_next, const int n_calls,
+                                   uint32_t *__restrict__ resume) {
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= a.B) return;
+    const uint32_t claimed = *claim_next; // claims handed out (it runs past B once every agent is taken)
+    uint32_t r = 0u;
+    if ((uint32_t)t < claimed) {
+        const NodeRec nd = a.nodes[(size_t)t * a.node_cap + a.state_pos[t]];
+        const bool pending = a.flags[t] == 0u && nd.act_end == 0u;
+        r = pending ? (pend[t].call | 0x80000000u) : (uint32_t)n_calls;
+    }
+    resume[t] = r;
+}
+void launch_pool_resume_scan(const Arenas &a, const PoolArgs &pool, int n_calls, uint32_t *resume, void *stream) {
+    k_pool_resume_scan<<<dim3((a.B + 255) / 256), dim3(256), 0, (hipStream_t)stream>>>(a, pool.pend, &pool.ctl->claim_next, n_calls, resume);
 }
 __global__ void k_probe_xcc(uint32_t *out) {
     if (threadIdx.x == 0) out[blockIdx.x] = pool_xcc_id();
@@ -74,21 +109,20 @@ bool pool_plan(const Arenas &a, const FusedEval &ev, PoolArgs *pool, uint32_t *d
 #elif defined(AZD_TU_ASYNC)
 #include "async_step.inc"
 template <class SP>
-static void l_async(const Arenas &a, const PersistArgs *d_args, int n_calls, unsigned long long *log_key,
+static void l_async(const Arenas &a, const PersistArgs *d_args, const StepLaunch &sl,
                     const float *params, const void *wpk, uint32_t dyn_stride, size_t dyn_bytes, hipStream_t st) {
     // dynamic LDS beyond the default 64 KB needs the attribute, which is per DEVICE (the current one): set on every
     // launch -- a host-side call, once per <= 1024 search calls -- so that engines on several devices in one process
     // all get it; the plans have already checked that the request fits beside the kernel's static LDS
     if (hipFuncSetAttribute((const void *)k_async<SP>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn_bytes) != hipSuccess) return; // sticky: the caller's hipGetLastError reports it
     const int n_wg = (a.B + PERSIST_WAVES - 1) / PERSIST_WAVES;
-    (void)hipMemsetAsync(log_key, 0xFF, (size_t)n_calls * sizeof(unsigned long long), st);
-    k_async<SP><<<dim3(n_wg), dim3(PERSIST_WAVES * 64), dyn_bytes, st>>>(d_args, n_calls, log_key, dyn_stride, params, a.state_vecs, a.h_theta, wpk);
-    k_argmin_log1<SP><<<dim3(1), dim3(64), SP::dyn_bytes(a), st>>>(a, n_calls, log_key);
+    k_async<SP><<<dim3(n_wg), dim3(PERSIST_WAVES * 64), dyn_bytes, st>>>(d_args, sl.n_calls, sl.log_key, dyn_stride, params, a.state_vecs, a.h_theta, wpk, sl.call_base, sl.resume);
+    k_argmin_log1<SP><<<dim3(1), dim3(64), SP::dyn_bytes(a), st>>>(a, sl.n_calls, sl.log_key, nullptr);
 }
-void launch_async(const Arenas &a, const PersistArgs *d_args, int n_calls, unsigned long long *log_key,
+void launch_async(const Arenas &a, const PersistArgs *d_args, const StepLaunch &sl,
                   const float *params, const void *wpk, uint32_t dyn_stride, size_t dyn_bytes, void *stream) {
-    if (a.space == SPACE_RAMSEY) return ramsey_launch_async(a, d_args, n_calls, log_key, params, wpk, dyn_stride, dyn_bytes, stream);
-    DISPATCH_KW(a, l_async, a, d_args, n_calls, log_key, params, wpk, dyn_stride, dyn_bytes, (hipStream_t)stream);
+    if (a.space == SPACE_RAMSEY) return ramsey_launch_async(a, d_args, sl, params, wpk, dyn_stride, dyn_bytes, stream);
+    DISPATCH_KW(a, l_async, a, d_args, sl, params, wpk, dyn_stride, dyn_bytes, (hipStream_t)stream);
 }
 // LDS plan of the asynchronous step (no evaluator buffers in LDS)
 bool async_plan(const Arenas &a, const FusedEval &ev, uint32_t *dyn_stride, size_t *dyn_bytes, const char **why) {
@@ -219,15 +253,15 @@ void launch_observe(const Arenas &a, uint32_t n_obs_tol, void *stream) {
     DISPATCH_KW(a, l_observe, a, n_obs_tol, (hipStream_t)stream);
 }
 template <class SP>
-static void l_persist(const Arenas &a, const PersistArgs *d_args, int n_calls, unsigned long long *log_key,
+static void l_persist(const Arenas &a, const PersistArgs *d_args, const StepLaunch &sl,
                       uint32_t *log_node, uint32_t dyn_stride, size_t dyn_bytes, hipStream_t st) {
     // dynamic LDS beyond the default 64 KB needs the attribute, which is per DEVICE (the current one): set on every
     // launch -- a host-side call, once per <= 1024 search calls -- so that engines on several devices in one process
     // all get it; the plans have already checked that the request fits beside the kernel's static LDS
     if (hipFuncSetAttribute((const void *)k_persist<SP>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn_bytes) != hipSuccess) return; // sticky: the caller's hipGetLastError reports it
     const int n_wg = (a.B + PERSIST_WAVES - 1) / PERSIST_WAVES;
-    k_persist<SP><<<dim3(n_wg), dim3(PERSIST_WAVES * 64), dyn_bytes, st>>>(d_args, n_calls, log_key, log_node, dyn_stride);
-    k_argmin_log<SP><<<dim3(1), dim3(64), SP::dyn_bytes(a), st>>>(a, n_calls, n_wg, log_key, log_node);
+    k_persist<SP><<<dim3(n_wg), dim3(PERSIST_WAVES * 64), dyn_bytes, st>>>(d_args, sl.n_calls, sl.log_key, log_node, dyn_stride, sl.call_base);
+    k_argmin_log<SP><<<dim3(1), dim3(64), SP::dyn_bytes(a), st>>>(a, sl.n_calls, n_wg, sl.log_key, log_node);
 }
 // LDS plan of the persistent step; returns false when the workgroup does not fit a CU
 bool persist_plan(const Arenas &a, const FusedEval &ev, uint32_t *dyn_stride, size_t *dyn_bytes, const char **why) {
@@ -262,10 +296,10 @@ bool persist_plan(const Arenas &a, const FusedEval &ev, uint32_t *dyn_stride, si
     *dyn_bytes = total;
     return true;
 }
-void launch_persist(const Arenas &a, const PersistArgs *d_args, int n_calls, unsigned long long *log_key,
+void launch_persist(const Arenas &a, const PersistArgs *d_args, const StepLaunch &sl,
                     uint32_t *log_node, uint32_t dyn_stride, size_t dyn_bytes, void *stream) {
-    if (a.space == SPACE_RAMSEY) return ramsey_launch_persist(a, d_args, n_calls, log_key, log_node, dyn_stride, dyn_bytes, stream);
-    DISPATCH_KW(a, l_persist, a, d_args, n_calls, log_key, log_node, dyn_stride, dyn_bytes, (hipStream_t)stream);
+    if (a.space == SPACE_RAMSEY) return ramsey_launch_persist(a, d_args, sl, log_node, dyn_stride, dyn_bytes, stream);
+    DISPATCH_KW(a, l_persist, a, d_args, sl, log_node, dyn_stride, dyn_bytes, (hipStream_t)stream);
 }
 template <class SP>
 static void l_modify_roots(const Arenas &a, uint64_t seed, uint64_t epoch, uint64_t first_agent, int kmin, int kmax,

@@ -69,6 +69,12 @@ class HashStreamModel(NablaModel):
         _lib.check(_lib.lib().azd_evaluator_create_hash_stream(C.byref(self._h), device, state_dim, action_dim, seed,
                                                                first_agent), "azd_evaluator_create_hash_stream")
 
+    def serve_from_pool_evaluators(self, on=True):
+        """test harness: the pool step's evaluator workgroups serve the rows (queues, early post, join) instead of the
+        searching wave itself; same values"""
+        _lib.check(_lib.lib().azd_debug_hash_stream_via_evaluators(self._h, int(on)), "azd_debug_hash_stream_via_evaluators")
+        return self
+
 
 class ActionModel(NablaModel):
     """ActionModel<M, BATCH, STATE, ACTION> (model/dfdx.rs:18-53): fp32 MLP

@@ -388,7 +388,11 @@ void *azd_engine_stream(azd_engine *e); /* hipStream_t the engine launches on */
 /* Which form of the step the last azd_engine_par_roll_out_episodes ran (identical results, very different
  * speed): the asynchronous CU-resident step, the lock-step CU-resident step, or one launch per phase and
  * call (external evaluators, models the in-kernel evaluator cannot take).  *reason (owned by the engine,
- * valid until the next call) says why a faster form was not taken, "" for AZD_STEP_ASYNC. */
+ * valid until the next call) says why a faster form was not taken, "" when the preferred one ran.
+ * The pool step needs its searcher and evaluator workgroups resident together: the grid is clamped to what the occupancy query
+ * reports, a device without room for one of each runs the asynchronous step, and a pool launch whose waits run into their
+ * bound (4 s without progress) is TAKEN OVER by the asynchronous step where every agent stands -- same results, the call
+ * succeeds, *reason says so and the engine stays with the asynchronous step. */
 #define AZD_STEP_NONE 0
 #define AZD_STEP_ASYNC 1
 #define AZD_STEP_BARRIER 2
@@ -400,6 +404,12 @@ int azd_engine_step_form(azd_engine *e, int *form, const char **reason);
 int azd_engine_pool_split(azd_engine *e, int *eval_wgs, int *search_wgs);
 /* HW_REG_XCC_ID read by every block of an n_blocks launch (the pool step keeps a tree on the XCD that first took it) */
 int azd_debug_probe_xcc(int device, uint32_t *out, int n_blocks);
+/* Test harness of the pool step: with `on`, a hash-stream evaluator's rows are served by the pool step's EVALUATOR workgroups
+ * (through the queues, the early post and the join counter, like the MLP's) instead of by the searching wave itself, so that
+ * whole launches of that machinery can be compared with the CPU oracle.  Same values either way.  Environment hooks of the
+ * same harness: AZD_POOL_DEBUG_ABORT_CALL=k (agent 0 raises the launch's abort flag after its k-th call: the take-over by the
+ * asynchronous step), AZD_POOL_MAX_RESIDENT=w (pretend the device holds w workgroups of the pool kernel at once). */
+int azd_debug_hash_stream_via_evaluators(azd_evaluator *ev, int on);
 
 /* Parity probe for the two f32 primitives the selection rule (tree/next_action.rs:70,81) depends
  * on bit-for-bit.  in: 2*n floats (pairs x, y); out: 4*n floats per pair:

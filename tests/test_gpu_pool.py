@@ -217,3 +217,160 @@ def test_pool_step_with_layered_states_and_sequence_paths(az, orc, kind):
         for i in range(B):
             assert_tree_equal(opt.get_tree(i), oe.export_tree(i), f"step {s} agent {i}")
     assert opt.step_form() == ("pool", "")
+
+
+# ---------------------------------------------------------------- whole epochs of the pool step against the ORACLE
+# The fixed prediction stream served by the pool step's evaluator workgroups (azd_debug_hash_stream_via_evaluators): the rows
+# take the MLP's way -- evaluator queues, early post, join counter, ready queues, agents migrating between waves and CUs --
+# while their values stay reproducible on the CPU, so whole 800-call launches can be checked against orc.Engine.
+_ORACLE_EPOCHS = {}
+
+
+def _oracle_two_epochs(orc, n, B, seed, calls, n_obs_tol, kmin, kmax):
+    key = (n, B, seed, calls)
+    if key in _ORACLE_EPOCHS:
+        return _ORACLE_EPOCHS[key]
+    A = orc.lib().orc_action_dim(n)
+    parents, permitted = orc.gen_roots(seed, 0, 0, B, n, kmin, kmax)
+    oe = orc.Engine(n, B, threads=16)
+    oe.new_begin(parents, permitted)
+    call = 0
+    oe.new_end(orc.hash_predictions(seed, 0, B, A, call))
+    snaps = []
+    for epoch in range(2):
+        improved = 0
+        for _ in range(calls):
+            oe.rollout_begin(*TOL_REF)
+            call += 1
+            improved += oe.rollout_end(orc.hash_predictions(seed, 0, B, A, call))
+        snap = dict(improved=improved, counters=oe.counters(), argmin=oe.argmin(), state_vecs=oe.state_vecs(),
+                    trees={i: oe.export_tree(i) for i in range(0, B, max(1, B // 24))})
+        if epoch == 0:
+            snap["obs"], snap["w"] = oe.observe(n_obs_tol)
+            snap["root_vecs"] = oe.state_vecs()
+            snap["new_roots"] = oe.modify_roots(seed, 0, 0, kmin, kmax)
+            oe.reset_begin(*snap["new_roots"])
+            call += 1
+            oe.reset_end(orc.hash_predictions(seed, 0, B, A, call))
+        snaps.append(snap)
+    _ORACLE_EPOCHS[key] = (parents, permitted, snaps)
+    return _ORACLE_EPOCHS[key]
+
+
+def _check_against_snapshot(opt, imp, snap, tag):
+    assert imp == snap["improved"], tag
+    c = opt.counters()
+    for k in MAIN_CTRS:
+        assert c[k] == snap["counters"][k], (tag, k, c[k], snap["counters"][k])
+    assert np.array_equal(opt.state_vecs(), snap["state_vecs"]), tag
+    for i, to in snap["trees"].items():
+        assert_tree_equal(opt.get_tree(i), to, f"{tag} agent {i}")
+    ag, ao = opt.argmin_data(), snap["argmin"]
+    assert ag.eval == ao["eval"] and np.array_equal(ag.state["parents"], ao["parents"]) and np.array_equal(ag.state["permitted"], ao["permitted"]), tag
+    assert ag.cost["lambda_1"] == ao["lambda1"] and len(ag.cost["matching"]) == ao["matching"], tag
+
+
+@pytest.mark.parametrize("B,early_post", [(256, "1"), (256, "2"), (3072, "1"), (3072, "2")])
+def test_pool_whole_epochs_against_the_oracle(az, orc, B, early_post, monkeypatch):
+    """800 calls in ONE k_pool launch, par_update_model + the device root policy, 800 more: trees, counters, improvement counts,
+    argmin, observations and the new roots against the oracle.  3072 agents are more than the searching waves the pool
+    gives them (every agent changes waves and CUs many times); early_post 1 / 2 = the row's request always / sometimes
+    leaves before the wave is through with the agent (PoolArgs::join decides who re-queues it)."""
+    monkeypatch.setenv("AZD_POOL_EARLY_POST", early_post)
+    n, seed, calls, n_obs_tol = 19, 12, 800, 200
+    space = az.ROTModifyParentsOnce(n)
+    kmin, kmax = space.default_permitted_range()
+    parents, permitted, snaps = _oracle_two_epochs(orc, n, B, seed, calls, n_obs_tol, kmin, kmax)
+    roots = space.generate_roots(seed, B)
+    assert np.array_equal(roots[0], parents) and np.array_equal(roots[1], permitted)
+    model = az.HashStreamModel(space.STATE_DIM, space.ACTION_DIM, seed).serve_from_pool_evaluators()
+    opt = az.NablaOptimizer.par_new(space, roots, model, B, pool_step=True)
+    imp = opt.par_roll_out_episodes(TOL_REF, n_calls=calls)
+    assert opt.step_form() == ("pool", "")
+    ev_wgs, se_wgs = opt.pool_split()
+    assert ev_wgs >= 1 and se_wgs >= 1
+    c = opt.counters()
+    assert c["EVAL_ROWS"] == c["EXPANSIONS"] > 0  # every row went through an evaluator workgroup
+    _check_against_snapshot(opt, imp, snaps[0], "epoch 0")
+    sv, obs, w = opt.observe(n_obs_tol)
+    assert np.array_equal(obs.view(np.uint32), snaps[0]["obs"].view(np.uint32)) and np.array_equal(w, snaps[0]["w"])
+    assert np.array_equal(sv, snaps[0]["root_vecs"])
+    rg = opt.c21_modify_roots(seed, 0, kmin, kmax)
+    assert np.array_equal(rg[0], snaps[0]["new_roots"][0]) and np.array_equal(rg[1], snaps[0]["new_roots"][1])
+    assert opt.par_update_model(n_obs_tol) == 0.0  # (the fixed stream has nothing to train)
+    opt.par_reset_trees_policy(seed, 0)
+    imp = opt.par_roll_out_episodes(TOL_REF, n_calls=calls)
+    assert opt.step_form() == ("pool", "")
+    _check_against_snapshot(opt, imp, snaps[1], "epoch 1")
+
+
+@pytest.mark.parametrize("model_kind", ["hash", "mlp"])
+def test_pool_abort_is_taken_over_by_the_async_step(az, orc, model_kind, monkeypatch):
+    """PoolCtl::abort (a wait ran into its bound) no longer fails the call: the asynchronous step takes the launch over
+    where every agent stands -- some through all calls, some waiting for a row that no evaluator will serve, some never
+    taken -- and the results are those of an undisturbed run.  The abort is raised by the test hook, mid-launch."""
+    n, B, seed, calls = 19, 300, 21, 60
+    space = az.ROTModifyParentsOnce(n)
+    roots = space.generate_roots(seed, B)
+
+    def make_model():
+        if model_kind == "hash":
+            return az.HashStreamModel(space.STATE_DIM, space.ACTION_DIM, seed).serve_from_pool_evaluators()
+        return az.ActionModel(B, space.STATE_DIM, space.ACTION_DIM, hidden=(256, 256, 256), seed=seed)
+
+    ref = az.NablaOptimizer.par_new(space, roots, make_model(), B, pool_step=False)
+    imp_ref = ref.par_roll_out_episodes(TOL_REF, n_calls=calls)
+    monkeypatch.setenv("AZD_POOL_DEBUG_ABORT_CALL", "7")
+    opt = az.NablaOptimizer.par_new(space, roots, make_model(), B, pool_step=True)
+    imp = opt.par_roll_out_episodes(TOL_REF, n_calls=calls)
+    form, why = opt.step_form()
+    assert form == "async" and why.startswith("pool step aborted"), (form, why)
+    same_engines(opt, imp, ref, imp_ref, range(B))
+    if model_kind == "hash":
+        oe = orc.Engine(n, B, threads=8)
+        oe.new_begin(*roots)
+        oe.new_end(orc.hash_predictions(seed, 0, B, space.ACTION_DIM, 0))
+        for call in range(1, calls + 1):
+            oe.rollout_begin(*TOL_REF)
+            oe.rollout_end(orc.hash_predictions(seed, 0, B, space.ACTION_DIM, call))
+        for i in range(0, B, 7):
+            assert_tree_equal(opt.get_tree(i), oe.export_tree(i), f"agent {i}")
+    # the engine is usable afterwards and stays with the asynchronous step
+    monkeypatch.delenv("AZD_POOL_DEBUG_ABORT_CALL")
+    imp2, imp2_ref = opt.par_roll_out_episodes(TOL_REF, n_calls=30), ref.par_roll_out_episodes(TOL_REF, n_calls=30)
+    form, why = opt.step_form()
+    assert form == "async" and "aborted" in why
+    same_engines(opt, imp2, ref, imp2_ref, range(0, B, 5))
+
+
+def test_pool_grid_is_clamped_to_what_the_device_holds(az, monkeypatch):
+    """searcher and evaluator workgroups wait for each other, so all of them must be resident: the grid follows the occupancy
+    query (here: a pretended capacity), whatever the overrides ask for; without room for one of each, the asynchronous step"""
+    n, B, seed, calls = 19, 512, 3, 40
+    space = az.ROTModifyParentsOnce(n)
+    roots = space.generate_roots(seed, B)
+    runs = {}
+    for cap, ev_wgs in ((None, None), ("40", None), ("24", "200"), ("1", None)):
+        if cap is None:
+            monkeypatch.delenv("AZD_POOL_MAX_RESIDENT", raising=False)
+        else:
+            monkeypatch.setenv("AZD_POOL_MAX_RESIDENT", cap)
+        if ev_wgs is None:
+            monkeypatch.delenv("AZD_POOL_EVAL_WGS", raising=False)
+        else:
+            monkeypatch.setenv("AZD_POOL_EVAL_WGS", ev_wgs)
+        model = az.ActionModel(B, space.STATE_DIM, space.ACTION_DIM, hidden=(256, 256, 256), seed=seed)
+        o = az.NablaOptimizer.par_new(space, roots, model, B, pool_step=True)
+        runs[(cap, ev_wgs)] = (o, o.par_roll_out_episodes(TOL_REF, n_calls=calls))
+    full = runs[(None, None)]
+    assert full[0].step_form() == ("pool", "")
+    for key, want in ((("40", None), 40), (("24", "200"), 24)):
+        o, imp = runs[key]
+        assert o.step_form() == ("pool", "")
+        ev, se = o.pool_split()
+        assert ev >= 1 and se >= 1 and ev + se <= want, (key, ev, se)
+        same_engines(o, imp, full[0], full[1], range(0, B, 37))
+    o, imp = runs[("1", None)]
+    form, why = o.step_form()
+    assert form == "async" and "resident" in why, (form, why)
+    same_engines(o, imp, full[0], full[1], range(0, B, 37))
