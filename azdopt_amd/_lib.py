@@ -84,7 +84,11 @@ def lib():
     vp, i32p, u64p, f32p = C.c_void_p, C.POINTER(C.c_int32), C.POINTER(C.c_uint64), C.POINTER(C.c_float)
 
     def sig(name, res, *args):
-        f = getattr(L, name)
+        f = getattr(L, name, None)
+        if f is None:
+            if "AZD_LIB" in os.environ:  # an older / experiment build selected by hand may lack the newer entry points
+                return
+            raise AttributeError("%s does not export %s" % (LIB_PATH, name))
         f.restype = res
         f.argtypes = list(args)
 

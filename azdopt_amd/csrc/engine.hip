@@ -966,6 +966,7 @@ int azd_engine_par_roll_out_episodes(azd_engine *e, const uint32_t *tol, int n_t
             now.a = e->a;
             now.tol = t;
             now.ev = fe;
+            now.ev.call_base = (fe.kind == 2 || fe.kind == 4) ? e->ev->calls : 0; // hash stream: index of the launch's first call
             now.pool = pl;
             if (e->pargs_valid && memcmp(&pa, &now, sizeof(now)) == 0) return AZD_OK;
             AZD_HIP(hipStreamSynchronize(e->stream)); // the pinned block may still be in flight from the copy before
@@ -998,10 +999,10 @@ int azd_engine_par_roll_out_episodes(azd_engine *e, const uint32_t *tol, int n_t
             }
             azd::StepLaunch sl;
             sl.n_calls = k;
-            sl.call_base = e->ev->calls;
             sl.log_key = e->d_log_key;
             sl.resume = nullptr;
             sl.ctl = use_pool ? pool.ctl : nullptr;
+            sl.hashed = fe.kind == 4;
             e->time_begin(0);
             if (use_pool) azd::launch_pool(e->a, e->d_pargs, sl, fe.params, fe.wpk, pool_blocks, dyn_stride, dyn_bytes, e->stream);
             else if (use_async) azd::launch_async(e->a, e->d_pargs, sl, fe.params, fe.wpk, dyn_stride, dyn_bytes, e->stream);

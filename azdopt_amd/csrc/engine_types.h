@@ -170,7 +170,7 @@ struct FusedEval {
     int kind;                // 0 not fusable (external), 1 TrivialModel, 2 hash stream, 3 MLP,
                              // 4 hash stream served by the pool step's EVALUATOR workgroups (test harness: the rows of the fixed
                              // prediction stream take the MLP's way through the queues, so the oracle can check whole launches)
-    uint64_t seed, first_agent; // hash stream (the index of a launch's first call is a kernel argument: StepLaunch::call_base)
+    uint64_t seed, first_agent, call_base; // hash stream; call_base = index of the launch's first call (0 for the other kinds, whose argument block then stays the same from launch to launch)
     const float *params;     // MLP: flat parameters (per layer W[out][in] then b[out])
     int n_layers;
     int dims[8];
@@ -245,19 +245,19 @@ struct PoolArgs {
     uint32_t eval_out_off; // offset (floats) of the head's output inside a row
     uint32_t eval_rows;    // rows an evaluator batch may hold: 16, or 32 (two MFMA row tiles per weight fragment)
     uint32_t *post_call;   // [B] FusedEval::kind 4 only: the call whose row the agent has posted (the evaluator hashes it)
-    uint32_t debug_abort_call; // test hook (AZD_POOL_DEBUG_ABORT_CALL): agent 0 raises PoolCtl::abort when it has completed this many calls; 0: off
+    uint32_t debug_abort_call; // test hook (AZD_POOL_DEBUG_ABORT_CALL = k): evaluator workgroup 0 raises PoolCtl::abort after its k-th batch; 0: off
 };
 
-// Per-launch values of the CU-resident step forms.  They travel as KERNEL ARGUMENTS, so that the argument block in device
-// memory (PersistArgs) stays what it was from launch to launch and is re-sent only when something in it changed.
+// Per-launch values of the CU-resident step forms that are not part of the argument block in device memory (PersistArgs, which
+// is re-sent only when something in it changed: with a model evaluator, never between the launches of an epoch).
 struct StepLaunch {
     int n_calls;
-    unsigned long long call_base;  // hash stream: index of the launch's first call (FusedEval kind 2 / 4)
     unsigned long long *log_key;   // [>= n_calls] per-call argmin candidates, all ones when the launch starts (k_argmin_log1 leaves them so)
     // k_async taking over from an aborted pool launch (engine.hip): [B] calls the agent has completed | 1u << 31 if its last
     // call ended on a new node whose prediction row / add_actions are still due.  Null: every agent starts at call 0.
     const uint32_t *resume;
     PoolCtl *ctl;                  // pool step: the control block k_argmin_log1 reports the abort flag from and clears; else null
+    int hashed;                    // pool step: FusedEval kind 4, the harness' instantiation of the kernel (k_pool<SP, true>)
 };
 
 struct PersistArgs { // argument block of the persistent step, read from device memory

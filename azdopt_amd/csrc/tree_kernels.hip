@@ -43,8 +43,13 @@ template <class SP>
 static void l_pool(const Arenas &a, const PersistArgs *d_args, const StepLaunch &sl, const float *params,
                    const void *wpk, int n_blocks, uint32_t dyn_stride, size_t dyn_bytes, hipStream_t st) {
     // the dynamic-LDS attribute is per device: set on every launch (see l_async)
-    if (hipFuncSetAttribute((const void *)k_pool<SP>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn_bytes) != hipSuccess) return;
-    k_pool<SP><<<dim3(n_blocks), dim3(PERSIST_WAVES * 64), dyn_bytes, st>>>(d_args, sl.n_calls, sl.log_key, dyn_stride, params, a.state_vecs, a.h_theta, wpk, sl.call_base);
+    if (sl.hashed) {
+        if (hipFuncSetAttribute((const void *)k_pool<SP, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn_bytes) != hipSuccess) return;
+        k_pool<SP, true><<<dim3(n_blocks), dim3(PERSIST_WAVES * 64), dyn_bytes, st>>>(d_args, sl.n_calls, sl.log_key, dyn_stride, params, a.state_vecs, a.h_theta, wpk);
+    } else {
+        if (hipFuncSetAttribute((const void *)k_pool<SP, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn_bytes) != hipSuccess) return;
+        k_pool<SP, false><<<dim3(n_blocks), dim3(PERSIST_WAVES * 64), dyn_bytes, st>>>(d_args, sl.n_calls, sl.log_key, dyn_stride, params, a.state_vecs, a.h_theta, wpk);
+    }
     k_argmin_log1<SP><<<dim3(1), dim3(64), SP::dyn_bytes(a), st>>>(a, sl.n_calls, sl.log_key, sl.ctl);
 }
 void launch_pool(const Arenas &a, const PersistArgs *d_args, const StepLaunch &sl, const float *params,
@@ -55,8 +60,8 @@ void launch_pool(const Arenas &a, const PersistArgs *d_args, const StepLaunch &s
 template <class SP>
 static void q_pool_resident(int *out, size_t dyn_bytes) {
     int nb = 0;
-    if (hipFuncSetAttribute((const void *)k_pool<SP>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn_bytes) != hipSuccess ||
-        hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, (const void *)k_pool<SP>, PERSIST_WAVES * 64, dyn_bytes) != hipSuccess) {
+    if (hipFuncSetAttribute((const void *)k_pool<SP, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn_bytes) != hipSuccess ||
+        hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, (const void *)k_pool<SP, false>, PERSIST_WAVES * 64, dyn_bytes) != hipSuccess) {
         (void)hipGetLastError();
         nb = 0;
     }
@@ -116,7 +121,7 @@ static void l_async(const Arenas &a, const PersistArgs *d_args, const StepLaunch
     // all get it; the plans have already checked that the request fits beside the kernel's static LDS
     if (hipFuncSetAttribute((const void *)k_async<SP>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn_bytes) != hipSuccess) return; // sticky: the caller's hipGetLastError reports it
     const int n_wg = (a.B + PERSIST_WAVES - 1) / PERSIST_WAVES;
-    k_async<SP><<<dim3(n_wg), dim3(PERSIST_WAVES * 64), dyn_bytes, st>>>(d_args, sl.n_calls, sl.log_key, dyn_stride, params, a.state_vecs, a.h_theta, wpk, sl.call_base, sl.resume);
+    k_async<SP><<<dim3(n_wg), dim3(PERSIST_WAVES * 64), dyn_bytes, st>>>(d_args, sl.n_calls, sl.log_key, dyn_stride, params, a.state_vecs, a.h_theta, wpk, sl.resume);
     k_argmin_log1<SP><<<dim3(1), dim3(64), SP::dyn_bytes(a), st>>>(a, sl.n_calls, sl.log_key, nullptr);
 }
 void launch_async(const Arenas &a, const PersistArgs *d_args, const StepLaunch &sl,
@@ -260,7 +265,7 @@ static void l_persist(const Arenas &a, const PersistArgs *d_args, const StepLaun
     // all get it; the plans have already checked that the request fits beside the kernel's static LDS
     if (hipFuncSetAttribute((const void *)k_persist<SP>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn_bytes) != hipSuccess) return; // sticky: the caller's hipGetLastError reports it
     const int n_wg = (a.B + PERSIST_WAVES - 1) / PERSIST_WAVES;
-    k_persist<SP><<<dim3(n_wg), dim3(PERSIST_WAVES * 64), dyn_bytes, st>>>(d_args, sl.n_calls, sl.log_key, log_node, dyn_stride, sl.call_base);
+    k_persist<SP><<<dim3(n_wg), dim3(PERSIST_WAVES * 64), dyn_bytes, st>>>(d_args, sl.n_calls, sl.log_key, log_node, dyn_stride);
     k_argmin_log<SP><<<dim3(1), dim3(64), SP::dyn_bytes(a), st>>>(a, sl.n_calls, n_wg, sl.log_key, log_node);
 }
 // LDS plan of the persistent step; returns false when the workgroup does not fit a CU
