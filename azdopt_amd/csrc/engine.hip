@@ -933,7 +933,25 @@ int azd_engine_par_roll_out_episodes(azd_engine *e, const uint32_t *tol, int n_t
         // (lane mode: measured +4 % at 8192 agents fp32, -4 % at config C, +-0 at config D -- within run-to-run noise: those
         // populations are bound by the searchers' capacity, not by the order they are served in.  Off unless asked for.)
         pool.ready_lanes = 0;
-        if (const char *env = getenv("AZD_POOL_READY_LANES")) pool.ready_lanes = atoi(env) != 0;
+        if (const char *env = getenv("AZD_POOL_READY_LANES")) pool.ready_lanes = atoi(env);
+        // Express mode (default with a model evaluator and a chip-sized grid): one searcher workgroup per XCD serves only the
+        // agents that lag behind the progress of their XCD's unfinished agents (by more than 1/16 of it), and every other wave
+        // takes one of those first when more of them wait than express waves stand by.  A launch lasts as long as its slowest
+        // agent's chain of calls; in that chain ~10 us per call were the agent waiting for a wave.  4096 agents fp32: 32.7-33.3
+        // -> 34.1-34.6 M expansions/s over whole epochs, 25.4-25.7 -> 26.0 in a 20-call launch (gpurun r3 sweeps: 8 / 16 / 24
+        // express workgroups, thresholds 1/4 .. 1/64, 4 / 8 / 16 waves each: 8-16 workgroups and 1/16-1/32 are the flat optimum,
+        // the waves per workgroup do not matter -- what helps is the place in the queue, not the emptier CU).
+        pool.n_express = (fe.kind >= 3 && n_search >= 64) ? 8 : 0;
+        pool.express_waves = 8;
+        pool.express_shift = 4;
+        if (const char *env = getenv("AZD_POOL_EXPRESS_WGS")) pool.n_express = atoi(env);
+        if (const char *env = getenv("AZD_POOL_EXPRESS_WAVES")) pool.express_waves = (uint32_t)atoi(env);
+        if (const char *env = getenv("AZD_POOL_EXPRESS_SHIFT")) pool.express_shift = (uint32_t)atoi(env);
+        if (pool.n_express > n_search / 2) pool.n_express = n_search / 2;
+        if (pool.n_express < 0) pool.n_express = 0;
+        if (pool.ready_lanes != 1) pool.ready_lanes = (pool.n_express > 0 && fe.kind >= 3) ? 2 : 0;
+        if (pool.ready_lanes != 2) pool.n_express = 0;
+        if (pool.express_waves < 1 || pool.express_waves > 16) pool.express_waves = 4;
         // Early post: the row leaves, and the evaluator is asked, before the wave computes the new node's cost and writes the
         // tree back (the agent is queued again by whoever is later, PoolArgs::join).  That takes ~15 us off an agent's cycle
         // and costs the wave a second drain of its stores (~1.5 us): +10 % where agents rarely wait for a wave (512..2048

@@ -220,7 +220,9 @@ struct PoolCtl {
     PoolQ evalq[2][POOL_XCDS];      // agents waiting for a prediction row, by home XCD; [0] = agents that lag behind, served first
     struct {
         uint32_t v, pad[31];
-    } sum_calls[POOL_XCDS], claimed[POOL_XCDS]; // calls completed by / agents living on each XCD: their ratio is the mean progress
+    } sum_calls[POOL_XCDS], claimed[POOL_XCDS], // calls completed by / agents living on each XCD: their ratio is the mean progress
+      done_x[POOL_XCDS],                        // agents of each XCD that are through all their calls (they no longer count for it)
+      max_lag[POOL_XCDS];                       // express mode: the largest lag behind the XCD's progress any of its agents has posted with
 };
 struct PendRec { // what a call that ended on a new node leaves for the add_actions that follows the evaluator
     uint32_t pos;
@@ -232,7 +234,13 @@ struct PoolArgs {
     PoolCtl *ctl;
     uint32_t *ready_slots; // [2][POOL_XCDS][qcap]  agent + 1, 0 = empty
     uint32_t *eval_slots;  // [2][POOL_XCDS][qcap]  (agent + 1) | home XCD << 24
-    int ready_lanes;       // 1: lane mode
+    int ready_lanes;       // 1: lane mode; 2: express mode -- the last n_express searcher workgroups run express_waves waves each (a wave
+                           // searches faster with its SIMD to itself: 39 us per call against 50 with 16 waves per CU) and serve ready[0]
+                           // only, which takes the agents that lag behind their XCD's progress: the launch lasts as long as the
+                           // slowest agent's chain of calls
+    int n_express;
+    uint32_t express_waves;
+    uint32_t express_shift; // an agent lags when its calls + 2 + (ref >> express_shift) < ref, ref = mean calls of the XCD's unfinished agents
     int early_post;        // the request for a prediction row leaves before the new node's cost is computed: 1 always, 2 when
                            // the wave had to wait for the agent (waves idle: latency-bound), 0 never
     uint32_t qcap;         // power of two >= 2 * B
