@@ -45,7 +45,7 @@ class EngineConfig(C.Structure):
                 ("node_capacity", C.c_int), ("arc_capacity", C.c_int), ("prediction_capacity", C.c_int),
                 ("first_agent", C.c_uint64), ("flags", C.c_uint32),
                 ("n_colors", C.c_int), ("clique_sizes", C.c_int * 4), ("color_weights", C.c_float * 4),
-                ("path_kind", C.c_int), ("layers", C.c_int)]
+                ("path_kind", C.c_int), ("layers", C.c_int), ("max_slots", C.c_int), ("dense_p", C.c_float)]
 
 
 class RamseyArgmin(C.Structure):  # ArgminData<RamseyCountsNoRecolor, TotalCounts<C>>

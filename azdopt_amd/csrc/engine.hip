@@ -152,6 +152,8 @@ struct azd_engine {
     bool graph_enabled = true;
     // dense-graph space: host-visible key width (action-id sets) and the packed roots as the device wants them
     int kw_host = 0;
+    int dense_slots = 0;              // 64 * a.KW: the most modifiable slots a root may bring
+    uint64_t *d_stage_slots = nullptr; // device root policy: the slot masks it drew, [B][(E + 63) / 64]
     std::vector<uint64_t> dense_packed;
     // pool step (agents multiplexed over searcher waves, evaluator workgroups on CUs of their own)
     bool pool_step = false;
@@ -249,8 +251,8 @@ int sync_status(azd_engine *e) {
 // rank -> action id table, and the mask of ranks still open (all k of them)
 int upload_dense_roots(azd_engine *e, const uint8_t *adj_bytes, const uint64_t *slots) {
     const Arenas &a = e->a;
-    const int n = a.n, E = a.E, KWH = e->kw_host;
-    const size_t per = 2 + MAX_NODE_ACTIONS / 4;
+    const int n = a.n, E = a.E, KWH = e->kw_host, KW = a.KW, MAXS = e->dense_slots;
+    const size_t per = (size_t)17 * KW; // [rank mask: KW words][rank -> action id: 64 KW x u16]
     e->dense_packed.assign((size_t)a.B * per, 0ull);
     for (int i = 0; i < a.B; ++i) {
         uint64_t adj[64];
@@ -273,8 +275,8 @@ int upload_dense_roots(azd_engine *e, const uint8_t *adj_bytes, const uint64_t *
         }
         const uint64_t *sl = slots + (size_t)i * KWH;
         uint64_t *pk = &e->dense_packed[(size_t)i * per];
-        uint16_t *tab = reinterpret_cast<uint16_t *>(pk + 2);
-        for (int r = 0; r < MAX_NODE_ACTIONS; ++r) tab[r] = 0xFFFFu;
+        uint16_t *tab = reinterpret_cast<uint16_t *>(pk + KW);
+        for (int r = 0; r < MAXS; ++r) tab[r] = 0xFFFFu;
         int k = 0;
         for (int pass = 0; pass < 2; ++pass) { // adds (absent edges), then deletes (present edges)
             int slot = 0;
@@ -283,8 +285,10 @@ int upload_dense_roots(azd_engine *e, const uint8_t *adj_bytes, const uint64_t *
                     if (!((sl[slot >> 6] >> (slot & 63)) & 1ull)) continue;
                     const bool present = (adj[v] >> u) & 1ull;
                     if (present != (pass == 1)) continue;
-                    if (k >= MAX_NODE_ACTIONS) {
-                        g_last_error = "more modifiable slots than a node can hold (128)";
+                    if (k >= MAXS) {
+                        char buf[160];
+                        snprintf(buf, sizeof(buf), "a root brings more than %d modifiable slots (azd_engine_config::max_slots sizes the keys)", MAXS);
+                        g_last_error = buf;
                         return AZD_ERR_INVALID_ARGUMENT;
                     }
                     tab[k++] = (uint16_t)(pass == 0 ? slot : E + slot);
@@ -297,8 +301,10 @@ int upload_dense_roots(azd_engine *e, const uint8_t *adj_bytes, const uint64_t *
                 return AZD_ERR_INVALID_ARGUMENT;
             }
         }
-        pk[0] = k >= 64 ? ~0ull : ((1ull << k) - 1ull);
-        pk[1] = k > 64 ? (k >= 128 ? ~0ull : ((1ull << (k - 64)) - 1ull)) : 0ull;
+        for (int w = 0; w < KW; ++w) {
+            const int hi = k - 64 * w;
+            pk[w] = hi <= 0 ? 0ull : (hi >= 64 ? ~0ull : ((1ull << hi) - 1ull));
+        }
     }
     AZD_HIP(hipMemcpyAsync(e->d_stage_parents, adj_bytes, (size_t)a.B * n * 8, hipMemcpyHostToDevice, e->stream));
     AZD_HIP(hipMemcpyAsync(e->d_stage_perm, e->dense_packed.data(), e->dense_packed.size() * 8, hipMemcpyHostToDevice, e->stream));
@@ -539,8 +545,9 @@ int azd_engine_create(azd_engine **out, const azd_engine_config *cfg, azd_evalua
     const bool ramsey = cfg->space_id == AZD_SPACE_RAMSEY;
     const bool dense = cfg->space_id == AZD_SPACE_DENSE;
     if (dense) {
-        if (cfg->n < 4 || cfg->n > AZD_DENSE_MAX_N || cfg->batch <= 0 || cfg->layers > 1) {
-            azd::g_last_error = "unsupported dense-graph space (need 4 <= n <= 64, no Layered wrapper)";
+        if (cfg->n < 4 || cfg->n > AZD_DENSE_MAX_N || cfg->batch <= 0 || cfg->layers > 1 || cfg->max_slots < 0 || cfg->max_slots > AZD_DENSE_MAX_SLOTS ||
+            !(cfg->dense_p >= 0.f && cfg->dense_p <= 1.f)) {
+            azd::g_last_error = "unsupported dense-graph space (need 4 <= n <= 64, no Layered wrapper, max_slots <= 1024, 0 <= dense_p <= 1)";
             return AZD_ERR_INVALID_ARGUMENT;
         }
     } else if (ramsey) {
@@ -583,7 +590,12 @@ int azd_engine_create(azd_engine **out, const azd_engine_config *cfg, azd_evalua
         a.E = azd::dense_edges(cfg->n);
         a.A = azd::dense_action_dim(cfg->n);
         a.S = azd::dense_state_dim(cfg->n);
-        a.KW = 2; // device keys: ranks of the root's (at most 128) modifiable slots
+        {   // device keys: ranks of the root's modifiable slots, in 2 / 4 / 10 / 16 words (the widths dense_kernels.hip is built for)
+            const int ms = cfg->max_slots > 0 ? cfg->max_slots : 128;
+            a.KW = ms <= 128 ? 2 : ms <= 256 ? 4 : ms <= 640 ? 10 : 16;
+            e->dense_slots = 64 * a.KW;
+        }
+        a.dense_p24 = (uint32_t)((cfg->dense_p > 0.f ? (double)cfg->dense_p : 0.2) * 16777216.0 + 0.5);
         a.eval_slope = azd::c21_eval_slope(cfg->n);
         e->kw_host = azd::dense_key_words(cfg->n);
     } else if (ramsey) {
@@ -662,7 +674,8 @@ int azd_engine_create(azd_engine **out, const azd_engine_config *cfg, azd_evalua
     if (dense) {
         TRY(e->alloc(&a.root_adj, B * 64));
         TRY(e->alloc(&a.cur_adj, B * 64));
-        TRY(e->alloc(&a.root_aid, B * azd::MAX_NODE_ACTIONS));
+        TRY(e->alloc(&a.root_aid, B * (size_t)e->dense_slots));
+        TRY(e->alloc(&e->d_stage_slots, B * (size_t)((a.E + 63) / 64)));
         TRY(e->alloc(&a.argmin_d, 1));
         TRY(e->alloc(&a.tutte_r, (size_t)a.E));
         std::vector<uint32_t> tr((size_t)a.E);
@@ -724,7 +737,7 @@ int azd_engine_create(azd_engine **out, const azd_engine_config *cfg, azd_evalua
         TRY(e->alloc(&e->d_log_node, (size_t)e->log_calls * n_wg));
     }
     TRY(e->alloc(&e->d_stage_parents, B * (size_t)(dense ? 8 * a.n : ramsey ? a.E : a.n)));
-    TRY(e->alloc(&e->d_stage_perm, B * (size_t)(dense ? 2 + azd::MAX_NODE_ACTIONS / 4 : a.KW)));
+    TRY(e->alloc(&e->d_stage_perm, B * (size_t)(dense ? 17 * a.KW : a.KW)));
     {
         hipError_t he = hipHostMalloc((void **)&e->h_status, sizeof(azd::StatusRec));
         if (he == hipSuccess) he = hipHostMalloc((void **)&e->h_argmin, sizeof(azd::ArgminRec));
@@ -1277,8 +1290,15 @@ int azd_engine_par_reset_trees(azd_engine *e, const uint8_t *parents, const uint
 static int c21_policy_args_ok(azd_engine *e, int kmin, int kmax) {
     if (!e || !e->initialised) return AZD_ERR_INVALID_ARGUMENT;
     if (e->a.space == azd::SPACE_DENSE) {
-        azd::g_last_error = "the device root policy is not built for the dense-graph space: pass new roots to par_reset_trees";
-        return AZD_ERR_UNSUPPORTED;
+        if (e->a.path_kind == azd::PATH_SEQUENCE) {
+            azd::g_last_error = "the device root policy of the dense-graph space handles ActionSet keys only";
+            return AZD_ERR_UNSUPPORTED;
+        }
+        if (kmin < 1 || kmax < kmin || kmax > e->a.E || kmax > e->dense_slots) {
+            azd::g_last_error = "dense root policy: need 1 <= kmin <= kmax <= min(E, 64 * key words) (azd_engine_config::max_slots)";
+            return AZD_ERR_INVALID_ARGUMENT;
+        }
+        return AZD_OK;
     }
     if (e->a.path_kind == azd::PATH_SEQUENCE && e->a.node_cap > 4096) {
         azd::g_last_error = "the device root policy handles sequence-keyed trees of at most 4096 nodes";
@@ -1297,7 +1317,9 @@ int azd_engine_par_reset_trees_c21(azd_engine *e, uint64_t seed, uint64_t epoch,
     if (!e->ev) return AZD_ERR_NO_EVALUATOR;
     AZD_HIP(hipSetDevice(e->cfg.device));
     const azd::Arenas &a = e->a;
-    azd::launch_c21_modify_roots(a, seed, epoch, e->cfg.first_agent, kmin, kmax, e->d_stage_parents, e->d_stage_perm, e->stream);
+    if (a.space == azd::SPACE_DENSE)
+        azd::dense_launch_modify_roots(a, seed, epoch, e->cfg.first_agent, kmin, kmax, e->d_stage_parents, e->d_stage_perm, e->d_stage_slots, e->stream);
+    else azd::launch_c21_modify_roots(a, seed, epoch, e->cfg.first_agent, kmin, kmax, e->d_stage_parents, e->d_stage_perm, e->stream);
     AZD_HIP(hipMemsetAsync(&a.status->failed, 0, sizeof(unsigned long long), e->stream));
     azd::launch_init_roots(a, e->d_stage_parents, e->d_stage_perm, e->stream);
     AZD_HIP(hipMemsetAsync(a.h_theta, 0, (size_t)a.B * a.A * 4, e->stream));
@@ -1313,6 +1335,18 @@ int azd_c21_modify_roots_dev(azd_engine *e, uint64_t seed, uint64_t epoch, int k
     if (!parents_out || !permitted_out) return AZD_ERR_INVALID_ARGUMENT;
     AZD_HIP(hipSetDevice(e->cfg.device));
     const azd::Arenas &a = e->a;
+    if (a.space == azd::SPACE_DENSE) { // roots_out: neighbourhoods (8 n bytes per root); permitted_out: slot masks in kw_host words per root
+        azd::dense_launch_modify_roots(a, seed, epoch, e->cfg.first_agent, kmin, kmax, e->d_stage_parents, e->d_stage_perm, e->d_stage_slots, e->stream);
+        const int ow = (a.E + 63) / 64;
+        std::vector<uint64_t> sl((size_t)a.B * ow);
+        AZD_HIP(hipMemcpyAsync(parents_out, e->d_stage_parents, (size_t)a.B * a.n * 8, hipMemcpyDeviceToHost, e->stream));
+        AZD_HIP(hipMemcpyAsync(sl.data(), e->d_stage_slots, sl.size() * 8, hipMemcpyDeviceToHost, e->stream));
+        AZD_HIP(hipStreamSynchronize(e->stream));
+        AZD_HIP(hipGetLastError());
+        memset(permitted_out, 0, (size_t)a.B * e->kw_host * 8);
+        for (int i = 0; i < a.B; ++i) memcpy(permitted_out + (size_t)i * e->kw_host, &sl[(size_t)i * ow], (size_t)ow * 8);
+        return AZD_OK;
+    }
     azd::launch_c21_modify_roots(a, seed, epoch, e->cfg.first_agent, kmin, kmax, e->d_stage_parents, e->d_stage_perm, e->stream);
     AZD_HIP(hipMemcpyAsync(parents_out, e->d_stage_parents, (size_t)a.B * (a.space == azd::SPACE_RAMSEY ? a.E : a.n), hipMemcpyDeviceToHost, e->stream));
     AZD_HIP(hipMemcpyAsync(permitted_out, e->d_stage_perm, (size_t)a.B * a.KW * 8, hipMemcpyDeviceToHost, e->stream));
@@ -1414,14 +1448,15 @@ int azd_engine_export_tree(azd_engine *e, int agent, float *c, float *c_star, ui
     if (na) AZD_HIP(hipMemcpy(arcs.data(), a.arcs + (size_t)agent * a.arc_cap, arcs.size() * sizeof(azd::ArcRec), hipMemcpyDeviceToHost));
     if (np) AZD_HIP(hipMemcpy(preds.data(), a.preds + (size_t)agent * a.pred_cap, preds.size() * sizeof(azd::PredRec), hipMemcpyDeviceToHost));
     if (keys && a.space == azd::SPACE_DENSE) { // device keys are sets of RANKS: back to action-id sets (kw_host words per node)
-        std::vector<uint64_t> rk((size_t)nn * 2);
-        uint16_t tab[azd::MAX_NODE_ACTIONS];
-        AZD_HIP(hipMemcpy(rk.data(), a.keys + (size_t)agent * a.node_cap * 2, rk.size() * 8, hipMemcpyDeviceToHost));
-        AZD_HIP(hipMemcpy(tab, a.root_aid + (size_t)agent * azd::MAX_NODE_ACTIONS, sizeof(tab), hipMemcpyDeviceToHost));
+        const int KW = a.KW, MAXS = e->dense_slots;
+        std::vector<uint64_t> rk((size_t)nn * KW);
+        std::vector<uint16_t> tab((size_t)MAXS);
+        AZD_HIP(hipMemcpy(rk.data(), a.keys + (size_t)agent * a.node_cap * KW, rk.size() * 8, hipMemcpyDeviceToHost));
+        AZD_HIP(hipMemcpy(tab.data(), a.root_aid + (size_t)agent * MAXS, tab.size() * 2, hipMemcpyDeviceToHost));
         memset(keys, 0, (size_t)nn * e->kw_host * 8);
         for (int i = 0; i < nn; ++i)
-            for (int r = 0; r < azd::MAX_NODE_ACTIONS; ++r)
-                if ((rk[(size_t)i * 2 + (r >> 6)] >> (r & 63)) & 1ull) keys[(size_t)i * e->kw_host + (tab[r] >> 6)] |= 1ull << (tab[r] & 63);
+            for (int r = 0; r < MAXS; ++r)
+                if ((rk[(size_t)i * KW + (r >> 6)] >> (r & 63)) & 1ull) keys[(size_t)i * e->kw_host + (tab[(size_t)r] >> 6)] |= 1ull << (tab[(size_t)r] & 63);
     } else if (keys) AZD_HIP(hipMemcpy(keys, a.keys + (size_t)agent * a.node_cap * a.KW, (size_t)nn * a.KW * 8, hipMemcpyDeviceToHost));
     for (int i = 0; i < nn; ++i) {
         if (c) c[i] = nodes[(size_t)i].c;
@@ -1451,20 +1486,21 @@ int azd_engine_agent_state(azd_engine *e, int agent, uint8_t *parents, uint64_t 
     AZD_HIP(hipStreamSynchronize(e->stream));
     const azd::Arenas &a = e->a;
     if (a.space == azd::SPACE_DENSE) { // `parents` receives the neighbourhoods (8 n bytes); masks are kw_host words
-        uint16_t tab[azd::MAX_NODE_ACTIONS];
-        uint64_t rem[2], pth[2];
-        AZD_HIP(hipMemcpy(tab, a.root_aid + (size_t)agent * azd::MAX_NODE_ACTIONS, sizeof(tab), hipMemcpyDeviceToHost));
-        AZD_HIP(hipMemcpy(rem, a.cur_perm + (size_t)agent * 2, 16, hipMemcpyDeviceToHost));
-        AZD_HIP(hipMemcpy(pth, a.cur_path + (size_t)agent * 2, 16, hipMemcpyDeviceToHost));
+        const int KW = a.KW, MAXS = e->dense_slots;
+        std::vector<uint16_t> tab((size_t)MAXS);
+        uint64_t rem[16], pth[16];
+        AZD_HIP(hipMemcpy(tab.data(), a.root_aid + (size_t)agent * MAXS, tab.size() * 2, hipMemcpyDeviceToHost));
+        AZD_HIP(hipMemcpy(rem, a.cur_perm + (size_t)agent * KW, (size_t)KW * 8, hipMemcpyDeviceToHost));
+        AZD_HIP(hipMemcpy(pth, a.cur_path + (size_t)agent * KW, (size_t)KW * 8, hipMemcpyDeviceToHost));
         if (parents) AZD_HIP(hipMemcpy(parents, a.cur_adj + (size_t)agent * 64, (size_t)a.n * 8, hipMemcpyDeviceToHost));
         if (permitted) memset(permitted, 0, (size_t)e->kw_host * 8);
         if (path) memset(path, 0, (size_t)e->kw_host * 8);
-        for (int r = 0; r < azd::MAX_NODE_ACTIONS; ++r) {
+        for (int r = 0; r < MAXS; ++r) {
             if (permitted && ((rem[r >> 6] >> (r & 63)) & 1ull)) { // open SLOTS, as in the packed root
-                const int slot = tab[r] % a.E;
+                const int slot = tab[(size_t)r] % a.E;
                 permitted[slot >> 6] |= 1ull << (slot & 63);
             }
-            if (path && ((pth[r >> 6] >> (r & 63)) & 1ull)) path[tab[r] >> 6] |= 1ull << (tab[r] & 63);
+            if (path && ((pth[r >> 6] >> (r & 63)) & 1ull)) path[tab[(size_t)r] >> 6] |= 1ull << (tab[(size_t)r] & 63);
         }
         if (state_pos) AZD_HIP(hipMemcpy(state_pos, a.state_pos + agent, 4, hipMemcpyDeviceToHost));
         if (lambda_1) AZD_HIP(hipMemcpy(lambda_1, a.cur_lambda + agent, 8, hipMemcpyDeviceToHost));

@@ -147,9 +147,10 @@ struct Arenas {
     int32_t *root_tot, *cur_tot;       // [B][4]
     RamseyArgminRec *argmin_r;
     // ---- dense-graph space (space_dense.inc); null for the other spaces.  E = N(N-1)/2 edge slots, A = 2E, S = 3E + 1,
-    // KW = 2 (keys over the ranks of the root's modifiable slots)
+    // KW = 2, 4, 10 or 16 (keys over the ranks of the root's modifiable slots: at most 64 KW of them)
     uint64_t *root_adj, *cur_adj; // [B][64] neighbourhood bitsets
-    uint16_t *root_aid;           // [B][MAX_NODE_ACTIONS] rank -> action id, ascending (0xFFFF beyond the root's k slots)
+    uint16_t *root_aid;           // [B][64 KW] rank -> action id, ascending (0xFFFF beyond the root's k slots)
+    uint32_t dense_p24;           // edge probability of a fresh root of the device root policy, x 2^24 (azd_engine_config::dense_p)
     DenseArgminRec *argmin_d;
     uint32_t *tutte_r; // [E] the Tutte matrix's entry of every edge slot (1 + key(slot) mod (P - 1), oracle/dense_graph.inc tutte_entry)
     // ---- path encoding P (az-discrete-opt/src/path/): PATH_SET = ActionSet (= ActionMultiset on
@@ -312,6 +313,9 @@ void launch_persist(const Arenas &a, const PersistArgs *d_args, const StepLaunch
                     uint32_t *log_node, uint32_t dyn_stride, size_t dyn_bytes, void *stream);
 void launch_c21_modify_roots(const Arenas &a, uint64_t seed, uint64_t epoch, uint64_t first_agent, int kmin, int kmax,
                              uint8_t *d_parents, uint64_t *d_perm, void *stream);
+// dense-graph space: d_packed = what k_init_roots takes (17 KW words per root), d_slots = the drawn slot masks ((E + 63) / 64 words per root)
+void dense_launch_modify_roots(const Arenas &a, uint64_t seed, uint64_t epoch, uint64_t first_agent, int kmin, int kmax,
+                               uint8_t *d_adj, uint64_t *d_packed, uint64_t *d_slots, void *stream);
 void launch_hash_predictions(float *d_out, int batch, int action_dim, uint64_t seed, uint64_t first_agent,
                              uint64_t call, void *stream);
 void launch_probe_cost(const uint8_t *d_parents, int n, int count, int reps, int full, double *d_lam, int *d_mu,

@@ -309,7 +309,7 @@ void launch_persist(const Arenas &a, const PersistArgs *d_args, const StepLaunch
 template <class SP>
 static void l_modify_roots(const Arenas &a, uint64_t seed, uint64_t epoch, uint64_t first_agent, int kmin, int kmax,
                            uint8_t *d_parents, uint64_t *d_perm, hipStream_t st) {
-    k_modify_roots<SP><<<dim3(a.B), dim3(64), SP::dyn_bytes(a), st>>>(a, seed, epoch, first_agent, kmin, kmax, d_parents, d_perm);
+    k_modify_roots<SP><<<dim3(a.B), dim3(64), SP::dyn_bytes(a), st>>>(a, seed, epoch, first_agent, kmin, kmax, d_parents, d_perm, d_perm);
 }
 void launch_c21_modify_roots(const Arenas &a, uint64_t seed, uint64_t epoch, uint64_t first_agent, int kmin, int kmax,
                              uint8_t *d_parents, uint64_t *d_perm, void *stream) {

@@ -34,7 +34,10 @@ class DenseArgminData:
     cost = Conjecture2Dot1Cost {lambda_1, matching number}"""
 
     def __init__(self, rec, space):
-        self.state = dict(adj=np.array(rec.adj[:space.n], np.uint64), permitted=np.array(rec.permitted[:space.KEY_WORDS], np.uint64))
+        slots = np.zeros(space.KEY_WORDS, np.uint64)  # the open slots as a bitmap over the E edge positions, in the host's key width
+        ow = (space.E + 63) // 64
+        slots[:ow] = rec.permitted[:ow]
+        self.state = dict(adj=np.array(rec.adj[:space.n], np.uint64), permitted=slots)
         self.cost = dict(lambda_1=rec.lambda_1, matching=[None] * rec.matching_size)  # the matching itself is not constructed
         self.eval = np.float32(rec.eval)
         self.agent, self.node = rec.agent, rec.node
@@ -72,6 +75,9 @@ class NablaOptimizer:
                                 | (_lib.ENGINE_ASYNC_STEP if (pool_step is False and async_step) else 0))
         cfg.path_kind = path.PATH_KIND
         cfg.layers = getattr(space, "layers", 1)
+        if space.SPACE_ID == _lib.SPACE_DENSE:
+            cfg.max_slots = space.MAX_SLOTS
+            cfg.dense_p = space.p
         if space.SPACE_ID == _lib.SPACE_RAMSEY:
             cfg.n_colors = space.C
             for i in range(space.C):

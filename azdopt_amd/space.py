@@ -154,13 +154,15 @@ class DenseGraphSpace(ActionsNeverRepeat, ActionOrderIndependent):
     (connected_bitset_graph/mod.rs: is_cut_edge, action_kinds, conjecture_2_1_cost; bitset_graph/space/action.rs:
     AddOrDeleteEdge indexing; 05-ah.rs:39-40: STATE = E + ACTION + 1) but no live NablaStateActionSpace over general
     graphs; the definition is in oracle/dense_graph.inc.  cost = Conjecture2Dot1Cost {lambda_1, matching number};
-    evaluate = squish(mu + lambda_1) with the bounds of 04-c21-tree.rs:58-74; at most 128 modifiable slots per root."""
+    evaluate = squish(mu + lambda_1) with the bounds of 04-c21-tree.rs:58-74.  `max_slots`: the most modifiable slots a root
+    may bring (= legal actions a node can hold; the engine sizes its keys from it: 128 / 256 / 640 / 1024); the drivers'
+    image is E // 2 (04-c21-tree.rs:85 permits up to half of ACTION_DIM), 128 keeps the keys at two words."""
 
     SPACE_ID = _lib.SPACE_DENSE
-    MAX_SLOTS = 128
 
-    def __init__(self, n, p=0.2):
+    def __init__(self, n, p=0.2, max_slots=128):
         self.n, self.p = int(n), float(p)
+        self.MAX_SLOTS = int(max_slots)
         self.E = self.n * (self.n - 1) // 2
         L = _lib.lib()
         self.STATE_DIM = L.azd_dense_state_dim(self.n)

@@ -97,7 +97,7 @@ int azd_ramsey_generate_roots(uint64_t seed, uint64_t epoch, uint64_t first_agen
 /* ------------------------------------------------------------------------- */
 #define AZD_SPACE_DENSE 3
 #define AZD_DENSE_MAX_N 64
-#define AZD_DENSE_MAX_SLOTS 128 /* modifiable edge slots of a root = legal actions a node can hold */
+#define AZD_DENSE_MAX_SLOTS 1024 /* modifiable edge slots of a root = legal actions a node can hold (azd_engine_config::max_slots) */
 int azd_dense_state_dim(int n);  /* 3E + 1 */
 int azd_dense_action_dim(int n); /* 2E: Add(e) = e, Delete(e) = E + e */
 int azd_dense_key_words(int n);  /* u64 words of an action-id set */
@@ -196,6 +196,12 @@ typedef struct azd_engine_config {
      * their earlier contents, as in the reference.  A root installed by par_new / par_reset_trees is a ring
      * of one (Layers::new). */
     int layers;
+    /* AZD_SPACE_DENSE only: the most modifiable edge slots a root may bring (= legal actions a node can hold); 0 = 128.  The
+     * engine keeps transposition keys over the ranks of a root's slots in 2, 4, 10 or 16 words: up to 128, 256, 640 or 1024
+     * slots (E / 2 = 612 at N = 50).  dense_p: edge probability of the fresh roots the device root policy draws (the `p` of
+     * azd_dense_generate_roots; 0 = 0.2). */
+    int max_slots;
+    float dense_p;
 } azd_engine_config;
 /* ActionSet (path/set.rs): key = set of actions taken; equal sets share a node (transpositions).
  * ActionMultiset (path/multiset.rs) coincides with it on ActionsNeverRepeat spaces: every count is 1,

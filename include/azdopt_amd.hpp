@@ -127,7 +127,9 @@ private:
 // STATE = E + ACTION + 1 at 05-ah.rs:39-40) but no live NablaStateActionSpace over general graphs; see azdopt_amd.h.
 class DenseGraphSpace {
 public:
-    explicit DenseGraphSpace(int n, double p = 0.2) : n_(n), p_(p) {}
+    // max_slots: the most modifiable edge slots a root may bring (azd_engine_config::max_slots; up to E / 2 in the drivers' image)
+    explicit DenseGraphSpace(int n, double p = 0.2, int max_slots = 128) : n_(n), p_(p), max_slots_(max_slots) {}
+    int max_slots() const { return max_slots_; }
     int n() const { return n_; }
     int E() const { return n_ * (n_ - 1) / 2; }
     int STATE_DIM() const { return azd_dense_state_dim(n_); }
@@ -147,11 +149,14 @@ public:
     void configure(azd_engine_config &cfg) const {
         cfg.space_id = AZD_SPACE_DENSE;
         cfg.n = n_;
+        cfg.max_slots = max_slots_;
+        cfg.dense_p = (float)p_;
     }
 
 private:
     int n_;
     double p_;
+    int max_slots_;
 };
 
 // ---------------------------------------------------------------- models (NablaModel, nabla/model/mod.rs:4-8)

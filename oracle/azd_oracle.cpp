@@ -356,6 +356,7 @@ struct Space {
     int kind = SPACE_C21;
     int layers = 1, S_inner = 0; /* Layered<L, _>: STATE_DIM = L * inner STATE_DIM (nabla/space/mod.rs:53) */
     int C = 0, E = 0, root_bytes = 0;
+    uint32_t p24 = 3355443; /* dense-graph space: edge probability of a fresh root, x 2^24 (0.2) */
     int sizes[MAXC] = {0, 0, 0, 0};
     float weights[MAXC] = {0, 0, 0, 0};
     /* space.rs:56-73 act; ramsey_counts/space.rs:71-86 */
@@ -1106,6 +1107,7 @@ orc_engine *orc_create_dense(int n, int batch, int threads) {
     engine_init(e, batch, threads);
     return e;
 }
+void orc_set_dense_p(orc_engine *e, uint32_t p24) { e->space.p24 = p24; }
 /* NablaOptimizer<RamseySpaceNoEdgeRecolor<B32, N, E, C>, M, ActionSet> (01-r333.rs:35-46, 02-r44.rs:35-47) */
 orc_engine *orc_create_ramsey(int n, int n_colors, const int *sizes, const float *weights, int batch, int threads) {
     if (n < 2 || n > MAXN || n_colors < 2 || n_colors > MAXC) return nullptr;
@@ -1277,7 +1279,10 @@ void orc_c21_modify_roots(orc_engine *e, uint64_t seed, uint64_t epoch, uint64_t
             if (num_permitted == kmax) {
                 int k = kmin + (int)below(r1, (uint32_t)(kmax - kmin + 1));
                 if (sp.kind == SPACE_RAMSEY) gen_ramsey_root(seed, domain, agent, sp.E, sp.C, sp.KW, k, po, mo);
-                else gen_one_root(seed, domain, agent, sp.n, k, po, mo, 0);
+                else if (sp.kind == SPACE_DENSE) { /* a fresh connected G(n, p) + k of its E slots */
+                    for (int w = 0; w < sp.KW; ++w) mo[w] = 0;
+                    gen_dense_root(seed, domain, agent, sp.n, k, sp.p24, reinterpret_cast<uint64_t *>(po), mo);
+                } else gen_one_root(seed, domain, agent, sp.n, k, po, mo, 0);
                 continue;
             }
             std::vector<const Path *> keep;
@@ -1287,7 +1292,7 @@ void orc_c21_modify_roots(orc_engine *e, uint64_t seed, uint64_t epoch, uint64_t
             for (uint32_t a : *p) sp.act(state, (int)a);
             int k = num_permitted + (int)below(r1, (uint32_t)(kmax - num_permitted + 1));
             pack_state(sp, state, po, scratch.data());
-            gen_permitted_of(seed, domain, agent, sp.kind == SPACE_RAMSEY ? sp.E : sp.A, sp.KW, k, mo, 0);
+            gen_permitted_of(seed, domain, agent, sp.kind == SPACE_C21 ? sp.A : sp.E, sp.KW, k, mo, 0); /* dense: k of the E edge slots */
         } else {
             float c_threshold = (c_root + 3.0f * c_root_star) / 4.0f;
             std::vector<const Path *> keep;
@@ -1297,7 +1302,7 @@ void orc_c21_modify_roots(orc_engine *e, uint64_t seed, uint64_t epoch, uint64_t
             for (uint32_t a : *p) sp.act(state, (int)a);
             int k = kmin + (int)below(r1, (uint32_t)(kmax - kmin + 1));
             pack_state(sp, state, po, scratch.data());
-            gen_permitted_of(seed, domain, agent, sp.kind == SPACE_RAMSEY ? sp.E : sp.A, sp.KW, k, mo, 0);
+            gen_permitted_of(seed, domain, agent, sp.kind == SPACE_C21 ? sp.A : sp.E, sp.KW, k, mo, 0);
         }
     }
 }

@@ -137,6 +137,8 @@ void orc_agent_state(orc_engine *e, int agent, uint8_t *parents, uint64_t *permi
 /* dims[n_layers+1]; hidden activations ReLU; final_act: 0 none, 1 ReLU, 2 Sigmoid */
 /* ---- the build-defined dense-graph space (oracle/dense_graph.inc; BASELINE configs[4]) */
 orc_engine *orc_create_dense(int n, int batch, int threads);
+/* edge probability (x 2^24) of the fresh roots orc_c21_modify_roots draws for the dense-graph space; default 0.2 */
+void orc_set_dense_p(orc_engine *e, uint32_t p24);
 void orc_gen_dense_roots(uint64_t seed, uint64_t epoch, uint64_t first_agent, int count, int n, int kmin, int kmax,
                          uint32_t p24, uint64_t *adj, uint64_t *slots);
 int orc_dense_matching_tutte(const uint64_t *adj, int n);     /* rank(Tutte over GF(2^31 - 1)) / 2 */

@@ -84,6 +84,7 @@ def lib():
     sig("orc_ramsey_counts_new", None, C.c_int, C.c_int, vp, vp, vp, vp)
     sig("orc_ramsey_act_sequence", None, C.c_int, C.c_int, vp, vp, vp, C.c_int, vp, vp)
     sig("orc_create_dense", vp, C.c_int, C.c_int, C.c_int)
+    sig("orc_set_dense_p", None, vp, C.c_uint32)
     sig("orc_gen_dense_roots", None, C.c_uint64, C.c_uint64, C.c_uint64, C.c_int, C.c_int, C.c_int, C.c_int, C.c_uint32, vp, vp)
     sig("orc_dense_matching_tutte", C.c_int, vp, C.c_int)
     sig("orc_dense_matching_reference", C.c_int, vp, C.c_int)
@@ -218,13 +219,14 @@ class Tree:
 class Engine:
     """NablaOptimizer-shaped driver of the oracle with an injectable model."""
 
-    def __init__(self, n, batch, threads=1, ramsey=None, path_kind=0, layers=1, dense=False):
+    def __init__(self, n, batch, threads=1, ramsey=None, path_kind=0, layers=1, dense=False, dense_p=0.2):
         """ramsey = (sizes, weights) selects RamseySpaceNoEdgeRecolor<B32, n, E, C>; default the c21 space.
         path_kind: 0 ActionSet / ActionMultiset, 1 ActionSequence / OrderedActionSet"""
         self.L = lib()
         self.n, self.B = n, batch
         if dense:
             self.h = self.L.orc_create_dense(n, batch, threads)
+            self.L.orc_set_dense_p(self.h, int(round(dense_p * (1 << 24))))  # fresh roots of the root policy
         elif ramsey is None:
             self.h = self.L.orc_create(n, batch, threads)
         else:

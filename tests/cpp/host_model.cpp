@@ -52,6 +52,19 @@ int main(int argc, char **argv) {
         const auto da = dopt.argmin_data();
         std::printf("dense improved %d eval %.9g lambda_1 %.17g matching %d loss %.9g\n", dimp, da.eval, da.lambda_1, da.matching_number,
                     dopt.par_update_model(3));
+        // N = 64 (AZD_DENSE_MAX_N): the argmin's open-slot bitmap is (E + 63) / 64 = 32 words, the host key width 63 -- the record
+        // must be copied by the former; then the device root policy (modify_root) with up to 200 slots per root
+        const azdopt::DenseGraphSpace big(64, 0.15, 200);
+        azdopt::TrivialModel triv(big.STATE_DIM(), big.ACTION_DIM());
+        auto bopt = azdopt::NablaOptimizer<azdopt::DenseGraphSpace>::par_new(big, big.generate_roots(seed, 4, 150, 200), triv, 4);
+        bopt.par_roll_out_episodes({{4, 2}, 1}, 6);
+        const auto ba = bopt.argmin_data();
+        size_t open = 0;
+        for (uint64_t w : ba.permitted) open += (size_t)__builtin_popcountll(w);
+        std::printf("dense64 slot words %zu open slots %zu eval %.9g\n", ba.permitted.size(), open, ba.eval);
+        bopt.par_reset_trees_policy(seed, 1, 150, 200);
+        bopt.par_roll_out_episodes({{4, 2}, 1}, 3);
+        std::printf("dense64 after policy eval %.9g\n", bopt.argmin_data().eval);
     } catch (const azdopt::Error &e) {
         std::fprintf(stderr, "azdopt error %d: %s\n", e.status(), e.what());
         return 1;

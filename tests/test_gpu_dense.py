@@ -31,12 +31,14 @@ def compare(opt, oe, agents, tag):
     assert np.array_equal(ag.state["adj"].view(np.uint8), ao["parents"]) and np.array_equal(ag.state["permitted"], ao["permitted"]), tag
 
 
-def run_dense_parity(az, orc, n, B, p, kmin, kmax, tol, steps, epochs, seed, check_every):
-    space = az.DenseGraphSpace(n, p)
+def run_dense_parity(az, orc, n, B, p, kmin, kmax, tol, steps, epochs, seed, check_every, max_slots=128, policy=False, **caps):
+    """policy: the epoch boundary is the drivers' modify_root on the DEVICE (par_reset_trees_policy: node choice in key
+    order, path replay, fresh connected roots, re-drawn slots) against the oracle's, instead of fresh roots from the host"""
+    space = az.DenseGraphSpace(n, p, max_slots=max_slots)
     model = az.HashStreamModel(space.STATE_DIM, space.ACTION_DIM, seed)
     roots = space.generate_roots(seed, B, kmin=kmin, kmax=kmax)
-    opt = az.NablaOptimizer.par_new(space, roots, model, B)
-    oe = orc.Engine(n, B, threads=8, dense=True)
+    opt = az.NablaOptimizer.par_new(space, roots, model, B, **caps)
+    oe = orc.Engine(n, B, threads=8, dense=True, dense_p=p)
     oe.new_begin(*roots)
     call = 0
     oe.new_end(orc.hash_predictions(seed, 0, B, space.ACTION_DIM, call))
@@ -58,8 +60,14 @@ def run_dense_parity(az, orc, n, B, p, kmin, kmax, tol, steps, epochs, seed, che
         sv, obs, w = opt.observe(2)
         oo, ow = oe.observe(2)
         assert np.array_equal(obs.view(np.uint32), oo.view(np.uint32)) and np.array_equal(w, ow) and np.array_equal(sv, oe.state_vecs())
-        roots = space.generate_roots(seed, B, epoch=epoch + 1, kmin=kmin, kmax=kmax)  # `modify_root`: fresh seeded roots from the host
-        opt.par_reset_trees(roots)
+        if policy:
+            roots = oe.modify_roots(seed, epoch, 0, kmin, kmax)
+            got = opt.modify_roots(seed, epoch, kmin, kmax)  # the policy alone: the new roots in the host's format
+            assert np.array_equal(got[0], roots[0]) and np.array_equal(got[1], roots[1]), epoch
+            opt.par_reset_trees_policy(seed, epoch, kmin, kmax)  # policy + reset without a host round trip
+        else:
+            roots = space.generate_roots(seed, B, epoch=epoch + 1, kmin=kmin, kmax=kmax)  # `modify_root`: fresh seeded roots from the host
+            opt.par_reset_trees(roots)
         oe.reset_begin(*roots)
         call += 1
         oe.reset_end(orc.hash_predictions(seed, 0, B, space.ACTION_DIM, call))
@@ -95,8 +103,29 @@ def test_dense_roots_are_validated(az):
     with pytest.raises(az.AzdError):
         az.NablaOptimizer.par_new(space, (lone.view(np.uint8).reshape(4, -1), slots), model, 4)
     opt = az.NablaOptimizer.par_new(space, (adj, slots), model, 4)
-    with pytest.raises(az.AzdError):  # the device root policy is not built for this space
-        opt.par_reset_trees_policy(0, 0)
+    with pytest.raises(az.AzdError):  # more slots than the engine's keys hold (max_slots = 128 -> 64 * 2 ranks)
+        opt.par_reset_trees_policy(0, 0, 5, 200)
+    many = az.DenseGraphSpace(30, 0.2)  # E = 435: a root with 300 slots does not fit the default key width
+    with pytest.raises(az.AzdError):
+        az.NablaOptimizer.par_new(many, many.generate_roots(0, 2, kmin=300, kmax=300), az.TrivialModel(many.STATE_DIM, many.ACTION_DIM), 2)
+
+
+@pytest.mark.parametrize("n,B,p,kmin,kmax,max_slots", [(8, 12, 0.4, 2, 10, 128), (8, 10, 0.5, 6, 6, 128), (20, 16, 0.2, 5, 150, 190)])
+def test_dense_device_root_policy(az, orc, n, B, p, kmin, kmax, max_slots):
+    """the drivers' modify_root (04-c21-tree.rs:172-206) for this space on the device: same new roots as the oracle's policy --
+    chosen node (BTreeMap order of the action-id sets = order of the rank sets), replayed path, fresh connected G(n, p) when
+    the root is at its slot limit (kmin == kmax forces that branch), re-drawn slot masks -- and the same trees afterwards"""
+    c = run_dense_parity(az, orc, n, B, p, kmin, kmax, ([6, 3], 2), steps=30, epochs=4, seed=9, check_every=15, max_slots=max_slots, policy=True)
+    assert c["EXPANSIONS"] > 0
+
+
+@pytest.mark.parametrize("max_slots,kmin,kmax", [(612, 300, 612), (1024, 700, 1000), (256, 129, 256)])
+def test_dense_n50_beyond_128_slots(az, orc, max_slots, kmin, kmax):
+    """roots with up to E / 2 = 612 modifiable slots (the drivers' image: up to half of the action space), and beyond: nodes
+    hold up to 64 KW predictions (KW = 4 / 10 / 16 key words), selection runs chunk by chunk (select_big), the keys are wider"""
+    c = run_dense_parity(az, orc, 50, 6, 0.1, kmin, kmax, ([30, 10, 5], 3), steps=60, epochs=2, seed=4, check_every=30, max_slots=max_slots,
+                         policy=True, prediction_capacity=131072)
+    assert c["EXPANSIONS"] > 300 and c["SUM_ACTIONS"] > 100 * c["SELECT_CALLS"]
 
 
 def test_dense_n50_with_the_512_wide_bf16_model(az, orc):

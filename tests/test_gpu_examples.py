@@ -160,4 +160,12 @@ def test_cpp_host_model_seam_matches_the_python_host(tmp_path):
     da = dopt.argmin_data()
     want.append("dense improved %d eval %.9g lambda_1 %.17g matching %d loss %.9g" % (
         dimp, da.eval, da.cost["lambda_1"], len(da.cost["matching"]), dopt.par_update_model(3)))
+    big = az.DenseGraphSpace(64, 0.15, max_slots=200)
+    bopt = az.NablaOptimizer.par_new(big, big.generate_roots(seed, 4, kmin=150, kmax=200), az.TrivialModel(big.STATE_DIM, big.ACTION_DIM), 4)
+    bopt.par_roll_out_episodes(([4, 2], 1), n_calls=6)
+    ba = bopt.argmin_data()
+    want.append("dense64 slot words %d open slots %d eval %.9g" % ((big.E + 63) // 64, sum(bin(int(w)).count("1") for w in ba.state["permitted"]), ba.eval))
+    bopt.par_reset_trees_policy(seed, 1, 150, 200)
+    bopt.par_roll_out_episodes(([4, 2], 1), n_calls=3)
+    want.append("dense64 after policy eval %.9g" % bopt.argmin_data().eval)
     assert r.stdout.splitlines() == want, r.stdout + "\n---\n" + "\n".join(want)

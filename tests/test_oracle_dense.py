@@ -123,3 +123,43 @@ def test_space_dimensions_roots_and_search(orc):
         # evaluate = squish(mu + lambda_1): slope 1 / (ceil(sqrt(N - 1)) + (N + 1) / 2 - 2) (04-c21-tree.rs:58-74)
         want = np.float32(1.0 / (3 + 5 - 2)) * ((np.float32(mu) + np.float32(lam)) - np.float32(2))
         assert t.c[node] == want
+
+
+def test_dense_root_policy_of_the_oracle_keeps_roots_legal(orc):
+    """the drivers' modify_root over the dense-graph space (orc_c21_modify_roots): every new root is a connected graph with
+    kmin..kmax of its E slots open; a root at its slot limit whose search found nothing better is replaced by a fresh G(n, p)"""
+    n, B, kmin, kmax, seed = 10, 24, 3, 12, 5
+    E = n * (n - 1) // 2
+    e = orc.Engine(n, B, threads=4, dense=True, dense_p=0.35)
+    adj, slots = orc.gen_dense_roots(seed, 0, 0, B, n, kmin, kmax, p=0.35)
+    e.new_begin(adj.view(np.uint8).reshape(B, -1), slots)
+    e.new_end(orc.hash_predictions(seed, 0, B, 2 * E, 0))
+    for call in range(1, 25):
+        e.rollout_begin([5, 3], 2)
+        e.rollout_end(orc.hash_predictions(seed, 0, B, 2 * E, call))
+    parents, permitted = e.modify_roots(seed, 0, 0, kmin, kmax)
+    new_adj = parents.view(np.uint64).reshape(B, n)
+    changed = 0
+    for i in range(B):
+        k = sum(bin(int(w)).count("1") for w in permitted[i])
+        assert kmin <= k <= kmax and not any(int(w) for w in permitted[i][(E + 63) // 64:]), (i, k)
+        a = new_adj[i]
+        seen, frontier = 1, 1
+        while frontier:
+            nxt = 0
+            for v in range(n):
+                if (frontier >> v) & 1:
+                    nxt |= int(a[v])
+            frontier = nxt & ~seen
+            seen |= nxt
+        assert seen == (1 << n) - 1, i  # connected
+        for v in range(n):
+            for u in range(n):
+                assert ((int(a[v]) >> u) & 1) == ((int(a[u]) >> v) & 1)
+        changed += int(not np.array_equal(a, adj[i]))
+    assert changed > 0  # some roots moved to a node of their tree (or were redrawn)
+    # the same call again gives the same roots (seeded), another epoch different slot draws
+    p2, m2 = e.modify_roots(seed, 0, 0, kmin, kmax)
+    assert np.array_equal(p2, parents) and np.array_equal(m2, permitted)
+    p3, m3 = e.modify_roots(seed, 1, 0, kmin, kmax)
+    assert not np.array_equal(m3, permitted)
