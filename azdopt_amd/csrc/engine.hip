@@ -677,13 +677,7 @@ int azd_engine_create(azd_engine **out, const azd_engine_config *cfg, azd_evalua
         TRY(e->alloc(&a.root_aid, B * (size_t)e->dense_slots));
         TRY(e->alloc(&e->d_stage_slots, B * (size_t)((a.E + 63) / 64)));
         TRY(e->alloc(&a.argmin_d, 1));
-        TRY(e->alloc(&a.tutte_r, (size_t)a.E));
-        std::vector<uint32_t> tr((size_t)a.E);
-        for (int s = 0; s < a.E; ++s) {
-            const uint64_t h = azd::splitmix64(azd::splitmix64(azd::splitmix64(azd::splitmix64(azd::DOMAIN_TUTTE) ^ (uint64_t)s) ^ 0ull) ^ 0ull);
-            tr[(size_t)s] = 1u + (uint32_t)(h % (uint64_t)(azd::TUTTE_P - 1u));
-        }
-        if (hipMemcpy(a.tutte_r, tr.data(), tr.size() * sizeof(uint32_t), hipMemcpyHostToDevice) != hipSuccess) return AZD_ERR_HIP;
+        TRY(e->alloc(&a.node_mate, B * (size_t)a.node_cap * 64));
     }
     if (ramsey) {
         TRY(e->alloc(&a.root_nbr, B * 128));

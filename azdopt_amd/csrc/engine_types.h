@@ -25,8 +25,6 @@ constexpr int SPACE_C21 = 1, SPACE_RAMSEY = 2, SPACE_DENSE = 3; // = AZD_SPACE_*
 constexpr int PRED_CHUNKS = 2;               // a node holds at most 64*PRED_CHUNKS legal actions
 constexpr int MAX_NODE_ACTIONS = 64 * PRED_CHUNKS;
 constexpr int FRONTIER_CAP = 256;            // LDS-staged cascade frontier per tree
-constexpr uint32_t TUTTE_P = 2147483647u;         // 2^31 - 1: field of the dense-graph space's Tutte matrix (space_dense.inc)
-constexpr uint64_t DOMAIN_TUTTE = 0x7475747465ull; // "tutte": stream of its entries
 constexpr int PATH_STACK = 32;               // nodes of the current path kept per agent, root first (deeper levels: not kept)
 constexpr int MAX_TOL = 32;
 constexpr int NUM_COUNTERS = 32; // 0..15 public counters, 16..24 phase ticks (AZD_PHASE_PROFILE builds), 25..27 evaluator service
@@ -152,7 +150,7 @@ struct Arenas {
     uint16_t *root_aid;           // [B][64 KW] rank -> action id, ascending (0xFFFF beyond the root's k slots)
     uint32_t dense_p24;           // edge probability of a fresh root of the device root policy, x 2^24 (azd_engine_config::dense_p)
     DenseArgminRec *argmin_d;
-    uint32_t *tutte_r; // [E] the Tutte matrix's entry of every edge slot (1 + key(slot) mod (P - 1), oracle/dense_graph.inc tutte_entry)
+    uint8_t *node_mate; // [B][node_cap][64] a maximum matching of every tree node's graph (0xFF: unmatched): a new node repairs its parent's
     // ---- path encoding P (az-discrete-opt/src/path/): PATH_SET = ActionSet (= ActionMultiset on
     // ActionsNeverRepeat spaces), PATH_SEQUENCE = ActionSequence (= OrderedActionSet): no transpositions
     int path_kind;

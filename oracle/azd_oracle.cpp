@@ -493,7 +493,7 @@ struct Space {
         Cost c;
         if (kind == SPACE_DENSE) { /* conjecture_2_1_cost, mod.rs:319-338 */
             c.lambda1 = dense_lambda1(s.adj, n);
-            c.mu = dense_matching_tutte(s.adj, n);
+            c.mu = dense_matching_exact(s.adj, n);
             return c;
         }
         if (kind == SPACE_RAMSEY) { /* ramsey_counts/space.rs:155-157 */
@@ -1057,6 +1057,7 @@ void orc_gen_dense_roots(uint64_t seed, uint64_t epoch, uint64_t first_agent, in
 }
 /* the dense-graph primitives, exposed for the golden-vector tests */
 int orc_dense_matching_tutte(const uint64_t *adj, int n) { return dense_matching_tutte(adj, n); }
+int orc_dense_matching_exact(const uint64_t *adj, int n) { return dense_matching_exact(adj, n); }
 int orc_dense_matching_reference(const uint64_t *adj, int n) { return dense_matching_reference(adj, n); }
 int orc_dense_is_cut_edge(const uint64_t *adj, int v, int u) { return dense_is_cut_edge(adj, v, u) ? 1 : 0; }
 double orc_dense_lambda1(const uint64_t *adj, int n) { return dense_lambda1(adj, n); }

@@ -141,7 +141,8 @@ orc_engine *orc_create_dense(int n, int batch, int threads);
 void orc_set_dense_p(orc_engine *e, uint32_t p24);
 void orc_gen_dense_roots(uint64_t seed, uint64_t epoch, uint64_t first_agent, int count, int n, int kmin, int kmax,
                          uint32_t p24, uint64_t *adj, uint64_t *slots);
-int orc_dense_matching_tutte(const uint64_t *adj, int n);     /* rank(Tutte over GF(2^31 - 1)) / 2 */
+int orc_dense_matching_tutte(const uint64_t *adj, int n);
+int orc_dense_matching_exact(const uint64_t *adj, int n); /* Edmonds: the matching number the space's cost uses */     /* rank(Tutte over GF(2^31 - 1)) / 2 */
 int orc_dense_matching_reference(const uint64_t *adj, int n); /* connected_bitset_graph/mod.rs:235-317, literally */
 int orc_dense_is_cut_edge(const uint64_t *adj, int v, int u); /* :47-71 */
 double orc_dense_lambda1(const uint64_t *adj, int n);

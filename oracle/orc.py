@@ -87,6 +87,7 @@ def lib():
     sig("orc_set_dense_p", None, vp, C.c_uint32)
     sig("orc_gen_dense_roots", None, C.c_uint64, C.c_uint64, C.c_uint64, C.c_int, C.c_int, C.c_int, C.c_int, C.c_uint32, vp, vp)
     sig("orc_dense_matching_tutte", C.c_int, vp, C.c_int)
+    sig("orc_dense_matching_exact", C.c_int, vp, C.c_int)
     sig("orc_dense_matching_reference", C.c_int, vp, C.c_int)
     sig("orc_dense_is_cut_edge", C.c_int, vp, C.c_int, C.c_int)
     sig("orc_dense_lambda1", C.c_double, vp, C.c_int)
@@ -147,6 +148,11 @@ def adjacency(n, edges):
 def dense_matching_tutte(adj):
     adj = np.ascontiguousarray(adj, np.uint64)
     return lib().orc_dense_matching_tutte(_p(adj), len(adj))
+
+
+def dense_matching_exact(adj):
+    adj = np.ascontiguousarray(adj, np.uint64)
+    return lib().orc_dense_matching_exact(_p(adj), len(adj))
 
 
 def dense_matching_reference(adj):
