@@ -162,6 +162,7 @@ def lib():
     sig("azd_debug_probe_xcc", C.c_int, C.c_int, vp, C.c_int)
     sig("azd_debug_hash_stream_via_evaluators", C.c_int, vp, C.c_int)
     sig("azd_debug_probe_math", C.c_int, C.c_int, vp, vp, C.c_int)
+    sig("azd_debug_gemm_bf16", C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, vp, vp, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, f32p)
     sig("azd_debug_probe_cost", C.c_int, C.c_int, vp, C.c_int, C.c_int, C.c_int, C.c_int, vp, vp, f32p)
     _LIB = L
     return L

@@ -5,6 +5,7 @@
 // Built with -ffp-contract=off like the other tree units.
 #include <hip/hip_runtime.h>
 
+#include "bf16.h"
 #include "engine_types.h"
 
 namespace azd {

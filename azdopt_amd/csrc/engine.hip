@@ -380,7 +380,7 @@ int upload_roots(azd_engine *e, const uint8_t *parents, const uint64_t *permitte
 
 int run_evaluator(azd_engine *e) {
     e->time_begin(1);
-    int st = e->ev->write_predictions_dev(e->a.B, e->a.state_vecs, e->a.h_theta, e->stream);
+    int st = e->ev->write_predictions_dev16(e->a.B, e->a.state_vecs, e->a.state_vecs16, e->a.S16, e->a.h_theta, e->stream);
     e->time_end();
     return st;
 }
@@ -678,6 +678,12 @@ int azd_engine_create(azd_engine **out, const azd_engine_config *cfg, azd_evalua
         TRY(e->alloc(&e->d_stage_slots, B * (size_t)((a.E + 63) / 64)));
         TRY(e->alloc(&a.argmin_d, 1));
         TRY(e->alloc(&a.node_mate, B * (size_t)a.node_cap * 64));
+        // a bf16 evaluator takes the state vectors as bf16 rows: this space's kernels write them beside the f32 rows (write_vec16)
+        if (ev && ev->input16_pitch() >= a.S) {
+            a.S16 = ev->input16_pitch();
+            TRY(e->alloc(&a.state_vecs16, B * (size_t)a.S16));
+            if (hipMemset(a.state_vecs16, 0, B * (size_t)a.S16 * 2) != hipSuccess) return AZD_ERR_HIP;
+        }
     }
     if (ramsey) {
         TRY(e->alloc(&a.root_nbr, B * 128));
@@ -1096,7 +1102,7 @@ int azd_engine_par_roll_out_episodes(azd_engine *e, const uint32_t *tol, int n_t
                 AZD_HIP(hipStreamBeginCapture(e->stream, hipStreamCaptureModeThreadLocal));
                 azd::launch_rollout(e->a, t, e->stream);
                 const uint64_t calls_before = e->ev->calls;
-                st = e->ev->write_predictions_dev(e->a.B, e->a.state_vecs, e->a.h_theta, e->stream);
+                st = e->ev->write_predictions_dev16(e->a.B, e->a.state_vecs, e->a.state_vecs16, e->a.S16, e->a.h_theta, e->stream);
                 e->ev->calls = calls_before;
                 azd::launch_add_actions(e->a, 0, e->stream);
                 azd::launch_argmin(e->a, 0, e->stream);

@@ -127,6 +127,8 @@ struct Arenas {
     uint32_t *cand_node;
     unsigned long long *counters; // [B][NUM_COUNTERS]
     float *state_vecs;      // [B][S]
+    uint16_t *state_vecs16; // [B][S16] the same rows as bf16 (RNE), zero beyond S, written beside the f32 rows by the spaces that have the
+    int S16;                // hook (SP::write_vec16): the bf16 evaluator's GEMM takes them as they are; null: no copy is kept
     float *h_theta;         // [B][A]
     float *obs;             // [B][A]
     float *weights;         // [B][A]

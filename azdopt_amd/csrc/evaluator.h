@@ -38,6 +38,13 @@ struct azd_evaluator {
     // NablaModel::update_model on device pointers; *loss is a host float, valid on return
     virtual int update_model_dev(int batch, const float *d_s, const float *d_o, const float *d_w, float *loss,
                                  hipStream_t st) = 0;
+    // The same with the input rows ALSO available as bf16 (RNE of the f32 rows, pitch `pitch16` elements, zero beyond state_dim):
+    // an evaluator with bf16 storage takes them as they are instead of converting the f32 rows.  input16_pitch(): the pitch it
+    // wants (0: it has no use for such rows).
+    virtual int write_predictions_dev16(int batch, const float *d_s, const uint16_t * /*d_s16*/, int /*pitch16*/, float *d_p, hipStream_t st) {
+        return write_predictions_dev(batch, d_s, d_p, st);
+    }
+    virtual int input16_pitch() { return 0; }
     // description for the persistent step (evaluator inside the kernel); false = not fusable
     virtual bool fused_desc(azd::FusedEval *) { return false; }
     // write_predictions_dev(batch) launches the same kernels with the same arguments on every call and allocates nothing

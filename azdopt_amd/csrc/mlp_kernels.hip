@@ -275,6 +275,8 @@ __global__ __launch_bounds__(256, MI == 1 ? 4 : 2) void k_gemm_bf16(const float 
     }
 }
 
+#include "gemm_bf16_glds.inc"
+
 // ---- bf16 weight storage: w16 = RNE(params) in 16-bit words, params_q = the same values widened back
 // to f32 (what the f32 GEMM path multiplies with, so that it computes what the bf16 MFMA path computes)
 __global__ void k_quantize_bf16(const float *__restrict__ p, size_t n, uint16_t *__restrict__ w16, float *__restrict__ q) {
@@ -442,6 +444,12 @@ struct MlpEvaluator : azd_evaluator {
     int cap_batch = 0;
     bool bf16 = false;             // AZD_STORAGE_BF16
     uint16_t *d_w16 = nullptr;     // bf16 copy of d_params (same offsets)
+    // the bf16 forward GEMM's operands (gemm_bf16_glds.inc): rows of pitch kp[l] = dims[l] rounded up to 64, zero beyond dims[l]
+    uint16_t *d_w16p = nullptr;    // weights, layer l at wp_off[l]: [dims[l + 1]][kp[l]]
+    std::vector<int64_t> wp_off;
+    std::vector<int> kp;
+    std::vector<uint16_t *> d_act16; // d_act16[l], l = 0 .. L-1: the input rows of layer l, [cap_batch][kp[l]] ([0]: the converted state vectors)
+    int n_cus = 256;
     float *d_params_q = nullptr;   // the bf16 values widened to f32 (GEMM path)
     float *d_xq = nullptr;         // input rows rounded to bf16 precision (GEMM path)
     float *d_split = nullptr;      // split-K parts of the largest weight gradient (gemm_dw)
@@ -454,6 +462,9 @@ struct MlpEvaluator : azd_evaluator {
     ~MlpEvaluator() override {
         (void)hipSetDevice(device);
         if (d_w16) (void)hipFree(d_w16);
+        if (d_w16p) (void)hipFree(d_w16p);
+        for (uint16_t *p : d_act16)
+            if (p) (void)hipFree(p);
         for (float *p : {d_params, d_grads, d_m, d_v, d_pred_train, d_delta_a, d_delta_b, d_partial, d_scalars, d_params_q, d_xq, d_wpk, d_split})
             if (p) (void)hipFree(p);
         for (float *p : d_act)
@@ -485,14 +496,50 @@ struct MlpEvaluator : azd_evaluator {
         }
         if (bf16 || d_w16) AZD_HIP(hipMalloc(&d_xq, (size_t)batch * dims[0] * 4));
         cap_batch = batch;
+        if (d_w16p) {
+            int st16 = alloc_act16();
+            if (st16) return st16;
+        }
         return AZD_OK;
     }
 
+    int alloc_act16() { // zeroed once: the kernels write columns < dims[l] only, the padding stays zero
+        for (uint16_t *&p : d_act16) {
+            if (p) (void)hipFree(p);
+            p = nullptr;
+        }
+        d_act16.assign((size_t)L, nullptr);
+        for (int l = 0; l < L; ++l) {
+            AZD_HIP(hipMalloc(&d_act16[(size_t)l], (size_t)cap_batch * kp[(size_t)l] * 2));
+            AZD_HIP(hipMemset(d_act16[(size_t)l], 0, (size_t)cap_batch * kp[(size_t)l] * 2));
+        }
+        return AZD_OK;
+    }
+    // The bf16 forward on the LDS-DMA GEMM (gemm_bf16_glds.inc): x16 = the input rows as bf16 with pitch kp[0] (the producer's own
+    // copy: azd_evaluator::write_predictions_dev16), or null: converted here from the f32 rows.  Same sums as k_gemm_bf16.
+    int forward16(int batch, const float *d_s, const uint16_t *x16, float *d_p, hipStream_t st) {
+        if (!x16) {
+            const int per = kp[0] / 4;
+            const size_t n = (size_t)batch * per;
+            k_rows_to_bf16<<<(unsigned)((n + 255) / 256), 256, 0, st>>>(d_s, dims[0], batch, dims[0], d_act16[0], kp[0]);
+            x16 = d_act16[0];
+        }
+        for (int l = 0; l < L; ++l) {
+            const bool last = l == L - 1;
+            void *y = last ? (void *)d_p : (void *)d_act16[(size_t)l + 1];
+            launch_gemm16(st, x16, kp[(size_t)l], d_w16p + wp_off[(size_t)l], kp[(size_t)l], y, last ? dims[(size_t)L] : kp[(size_t)l + 1], batch,
+                          dims[(size_t)l + 1], kp[(size_t)l], last ? final_act : AZD_ACT_RELU, last ? 0 : 1, d_params + b_off[(size_t)l], n_cus);
+            x16 = d_act16[(size_t)(last ? l : l + 1)];
+        }
+        AZD_HIP(hipGetLastError());
+        return AZD_OK;
+    }
     // quant: inference with bf16-stored weights and activations (f32 accumulate); training always runs on
     // the f32 master weights
     int forward(int batch, const float *d_s, float *d_p, hipStream_t st, bool quant = false) {
         const float *x = d_s;
         const float *P = quant ? d_params_q : d_params;
+        if (quant && d_w16p && !getenv("AZD_GEMM_OLD")) return forward16(batch, d_s, nullptr, d_p, st);
         bool mfma16 = quant; // the bf16 MFMA GEMM takes row pitches in multiples of 4
         for (int l = 0; l < L && mfma16; ++l) mfma16 = dims[(size_t)l] % 4 == 0 && w_off[(size_t)l] % 4 == 0;
         if (mfma16) {
@@ -539,6 +586,16 @@ struct MlpEvaluator : azd_evaluator {
         calls += 1;
         return forward(batch, d_s, d_p, st, bf16);
     }
+
+    int write_predictions_dev16(int batch, const float *d_s, const uint16_t *d_s16, int pitch16, float *d_p, hipStream_t st) override {
+        if (!bf16 || !d_w16p || !d_s16 || pitch16 != kp[0] || getenv("AZD_GEMM_OLD")) return write_predictions_dev(batch, d_s, d_p, st);
+        AZD_HIP(hipSetDevice(device));
+        int s = ensure_batch(batch);
+        if (s) return s;
+        calls += 1;
+        return forward16(batch, d_s, d_s16, d_p, st);
+    }
+    int input16_pitch() override { return (bf16 && d_w16p) ? kp[0] : 0; }
 
     // dfdx.rs:86-131
     int update_model_dev(int batch, const float *d_s, const float *d_o, const float *d_w, float *loss, hipStream_t st) override {
@@ -632,6 +689,11 @@ struct MlpEvaluator : azd_evaluator {
     }
     void requantize(hipStream_t st) {
         k_quantize_bf16<<<(unsigned)((n_params + 255) / 256), 256, 0, st>>>(d_params, (size_t)n_params, d_w16, d_params_q);
+        for (int l = 0; l < L; ++l) { // the padded rows of the LDS-DMA GEMM
+            const size_t n = (size_t)dims[(size_t)l + 1] * (kp[(size_t)l] / 4);
+            k_rows_to_bf16<<<(unsigned)((n + 255) / 256), 256, 0, st>>>(d_params + w_off[(size_t)l], dims[(size_t)l], dims[(size_t)l + 1], dims[(size_t)l],
+                                                                         d_w16p + wp_off[(size_t)l], kp[(size_t)l]);
+        }
     }
     // AZD_STORAGE_BF16: inference reads bf16 copies of the weights (refreshed after every optimiser step),
     // the optimiser keeps f32 master weights
@@ -643,6 +705,21 @@ struct MlpEvaluator : azd_evaluator {
         if (dtype == AZD_STORAGE_BF16 && !d_w16) {
             AZD_HIP(hipMalloc(&d_w16, (size_t)n_params * 2));
             AZD_HIP(hipMalloc(&d_params_q, (size_t)n_params * 4));
+            {
+                kp.clear();
+                wp_off.clear();
+                int64_t off = 0;
+                for (int l = 0; l < L; ++l) {
+                    kp.push_back((dims[(size_t)l] + 63) / 64 * 64);
+                    wp_off.push_back(off);
+                    off += (int64_t)dims[(size_t)l + 1] * kp[(size_t)l];
+                }
+                AZD_HIP(hipMalloc(&d_w16p, (size_t)off * 2));
+                hipDeviceProp_t prop;
+                if (hipGetDeviceProperties(&prop, device) == hipSuccess) n_cus = prop.multiProcessorCount;
+                int st16 = alloc_act16();
+                if (st16) return st16;
+            }
             AZD_HIP(hipMalloc(&d_xq, (size_t)cap_batch * dims[0] * 4));
         }
         bf16 = dtype == AZD_STORAGE_BF16;
@@ -755,3 +832,32 @@ azd_evaluator *make_mlp_evaluator(int device, int max_batch, int state_dim, int 
 }
 
 } // namespace azd
+
+// the bf16 forward GEMM in isolation (tools/time_gemm.py, tests): device pointers, A [M][Kp] and W [N][Kp] bf16 with Kp a
+// multiple of 64 (zero beyond the real K), Y f32 or bf16 [M][ldy]; *ms = mean GPU time of `reps` launches after one warm-up
+extern "C" int azd_debug_gemm_bf16(int device, int M, int N, int Kp, const void *d_a, const void *d_w, const float *d_bias, void *d_y, int ldy,
+                                   int out_bf16, int act, int reps, float *ms) {
+    if (M <= 0 || N <= 0 || Kp <= 0 || Kp % 64 != 0 || !d_a || !d_w || !d_y || reps < 1) return AZD_ERR_INVALID_ARGUMENT;
+    AZD_HIP(hipSetDevice(device));
+    hipDeviceProp_t prop;
+    AZD_HIP(hipGetDeviceProperties(&prop, device));
+    hipStream_t st;
+    AZD_HIP(hipStreamCreate(&st));
+    hipEvent_t e0, e1;
+    AZD_HIP(hipEventCreate(&e0));
+    AZD_HIP(hipEventCreate(&e1));
+    azd::launch_gemm16(st, (const uint16_t *)d_a, Kp, (const uint16_t *)d_w, Kp, d_y, ldy, M, N, Kp, act, out_bf16, d_bias, prop.multiProcessorCount);
+    AZD_HIP(hipEventRecord(e0, st));
+    for (int r = 0; r < reps; ++r)
+        azd::launch_gemm16(st, (const uint16_t *)d_a, Kp, (const uint16_t *)d_w, Kp, d_y, ldy, M, N, Kp, act, out_bf16, d_bias, prop.multiProcessorCount);
+    AZD_HIP(hipEventRecord(e1, st));
+    AZD_HIP(hipStreamSynchronize(st));
+    AZD_HIP(hipGetLastError());
+    float t = 0.f;
+    AZD_HIP(hipEventElapsedTime(&t, e0, e1));
+    if (ms) *ms = t / (float)reps;
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+    (void)hipStreamDestroy(st);
+    return AZD_OK;
+}

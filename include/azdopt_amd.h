@@ -427,6 +427,12 @@ int azd_debug_probe_math(int device, const float *in, float *out, int n);
 int azd_debug_probe_cost(int device, const uint8_t *parents, int n, int count, int reps, int full,
                          double *lambda_1, int *matching_size, float *ms);
 
+/* The evaluator's bf16 forward GEMM in isolation (timing, tests): Y[M, N] = act(A[M, K] . W[N, K]^T + bias) on device
+ * pointers; A and W are bf16 rows of pitch Kp (a multiple of 64, zero beyond K), Y f32 or bf16 with pitch ldy;
+ * *ms = mean GPU time of `reps` launches. */
+int azd_debug_gemm_bf16(int device, int M, int N, int Kp, const void *d_a, const void *d_w, const float *d_bias, void *d_y, int ldy,
+                        int out_bf16, int act, int reps, float *ms);
+
 #ifdef __cplusplus
 }
 #endif

@@ -149,6 +149,11 @@ def test_dense_n50_with_the_512_wide_bf16_model(az, orc):
     assert opt.step_form()[0] == "per_call"
     for i in range(B):
         assert_tree_equal(opt.get_tree(i), oe.export_tree(i), f"agent {i}")
+    # the engine handed the evaluator the state vectors as bf16 rows written by the search kernels themselves (write_vec16);
+    # the evaluator's own entry point converts the f32 rows: same prediction rows bit for bit
+    again = np.zeros((B, space.ACTION_DIM), np.float32)
+    model.write_predictions(opt.state_vecs(), again)
+    assert np.array_equal(again.view(np.uint32), opt.predictions().view(np.uint32))
     loss = opt.par_update_model(2)
     assert np.isfinite(loss) and loss >= 0
 
