@@ -30,11 +30,11 @@ static void l_init_roots(const Arenas &a, const uint8_t *p, const uint64_t *m, h
 }
 template <class SP>
 static void l_add_actions(const Arenas &a, int root_mode, hipStream_t st) {
-    k_add_actions<SP><<<dim3(a.B), dim3(64), SP::dyn_bytes(a), st>>>(a, root_mode);
+    k_add_actions<SP><<<dim3(a.tn ? a.tn : a.B), dim3(64), SP::dyn_bytes(a), st>>>(a, root_mode);
 }
 template <class SP>
 static void l_rollout(const Arenas &a, const TolTable &tol, hipStream_t st) {
-    k_rollout<SP><<<dim3(a.B), dim3(64), SP::dyn_bytes(a), st>>>(a, tol);
+    k_rollout<SP><<<dim3(a.tn ? a.tn : a.B), dim3(64), SP::dyn_bytes(a), st>>>(a, tol);
 }
 template <class SP>
 static void l_argmin(const Arenas &a, int init_mode, hipStream_t st) {
@@ -56,6 +56,13 @@ void dense_launch_init_roots(const Arenas &a, const uint8_t *d_adj, const uint64
 void dense_launch_add_actions(const Arenas &a, int root_mode, void *stream) { DISPATCH_DKW(a, l_add_actions, a, root_mode, (hipStream_t)stream); }
 void dense_launch_rollout(const Arenas &a, const TolTable &tol, void *stream) { DISPATCH_DKW(a, l_rollout, a, tol, (hipStream_t)stream); }
 void dense_launch_argmin(const Arenas &a, int init_mode, void *stream) { DISPATCH_DKW(a, l_argmin, a, init_mode, (hipStream_t)stream); }
+template <class SP>
+static void l_argmin_log(const Arenas &a, int n_calls, unsigned long long *log_key, hipStream_t st) {
+    k_argmin_log1<SP><<<dim3(1), dim3(64), SP::dyn_bytes(a), st>>>(a, n_calls, log_key, nullptr);
+}
+void dense_launch_argmin_log(const Arenas &a, int n_calls, unsigned long long *log_key, void *stream) {
+    DISPATCH_DKW(a, l_argmin_log, a, n_calls, log_key, (hipStream_t)stream);
+}
 void dense_launch_observe(const Arenas &a, uint32_t n_obs_tol, void *stream) { DISPATCH_DKW(a, l_observe, a, n_obs_tol, (hipStream_t)stream); }
 void dense_launch_modify_roots(const Arenas &a, uint64_t seed, uint64_t epoch, uint64_t first_agent, int kmin, int kmax,
                                uint8_t *d_adj, uint64_t *d_packed, uint64_t *d_slots, void *stream) {

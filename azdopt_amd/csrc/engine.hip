@@ -150,6 +150,14 @@ struct azd_engine {
     azd::TolTable call_graph_tol{};
     uint64_t call_graph_layout = 0;
     bool graph_enabled = true;
+    // launch-per-phase form over sub-populations, each on a stream of its own with its call captured in a graph: the kernels of
+    // one sub-population's call overlap the slowest agents of another's (a roll-out launch lasts as long as its slowest agent)
+    static constexpr int MAX_SUBS = 8;
+    hipStream_t sub_stream[MAX_SUBS] = {};
+    hipEvent_t sub_fork = nullptr, sub_join[MAX_SUBS] = {};
+    hipGraphExec_t sub_graph[MAX_SUBS] = {};
+    int sub_graph_n = 0;
+    uint32_t *d_call_ctr = nullptr; // [MAX_SUBS] calls a sub-population has logged in the current run
     // dense-graph space: host-visible key width (action-id sets) and the packed roots as the device wants them
     int kw_host = 0;
     int dense_slots = 0;              // 64 * a.KW: the most modifiable slots a root may bring
@@ -722,6 +730,7 @@ int azd_engine_create(azd_engine **out, const azd_engine_config *cfg, azd_evalua
         TRY(e->alloc(&e->pool.stamp, B));
         TRY(e->alloc(&e->pool.post_call, B));
         TRY(e->alloc(&e->d_resume, B));
+        TRY(e->alloc(&e->d_call_ctr, (size_t)azd_engine::MAX_SUBS));
     }
     e->log_calls = 1024;
     {
@@ -775,6 +784,12 @@ int azd_engine_destroy(azd_engine *e) {
     if (e->h_pargs) (void)hipHostFree(e->h_pargs);
     if (e->d_pool) (void)hipFree(e->d_pool);
     if (e->call_graph) (void)hipGraphExecDestroy(e->call_graph);
+    for (int i = 0; i < azd_engine::MAX_SUBS; ++i) {
+        if (e->sub_graph[i]) (void)hipGraphExecDestroy(e->sub_graph[i]);
+        if (e->sub_join[i]) (void)hipEventDestroy(e->sub_join[i]);
+        if (e->sub_stream[i]) (void)hipStreamDestroy(e->sub_stream[i]);
+    }
+    if (e->sub_fork) (void)hipEventDestroy(e->sub_fork);
     for (auto &it : e->ev_inflight) {
         (void)hipEventDestroy(it.second.first);
         (void)hipEventDestroy(it.second.second);
@@ -1094,8 +1109,87 @@ int azd_engine_par_roll_out_episodes(azd_engine *e, const uint32_t *tol, int n_t
         // step").  Not while per-launch timing is on (the events would be captured too), nor for evaluators whose
         // kernels take the call index.
         const bool graphable = e->graph_enabled && !e->timing && n_calls >= 2 && e->ev->replayable(e->a.B);
-        if (graphable) {
-            if (!e->call_graph || memcmp(&e->call_graph_tol, &t, sizeof(t)) != 0 || e->call_graph_layout != e->ev->layout_version) {
+        // Sub-populations: a roll-out launch lasts as long as its slowest agent (config E: 1.2 ms against a mean agent's 0.06), so
+        // the population is cut into S parts, each with a stream and a graph of its own (roll-out, model rows, add_actions,
+        // candidates into the per-call log); the parts run n_calls calls independently -- trees never exchange data and the
+        // model is constant -- and one part's kernels fill the CUs another part's stragglers leave idle.  The per-call argmin
+        // is replayed from the log afterwards, as in the CU-resident forms.  Needs an evaluator whose rows may run concurrently.
+        // (Config E, 8192 agents: 1 / 2 / 4 / 8 parts -> 11.7 / 12.4 / 8.0 / 6.0 M expansions/s: every part adds seven graph nodes per
+        // call for the host to enqueue, and beyond two parts the host, not the GPU, sets the pace.)
+        int n_subs = (e->a.B >= 2048 && e->ev->rows_concurrent()) ? 2 : 1;
+        if (const char *env = getenv("AZD_PER_CALL_STREAMS")) n_subs = atoi(env);
+        if (n_subs > azd_engine::MAX_SUBS) n_subs = azd_engine::MAX_SUBS;
+        if (n_subs > 1 && (!e->ev->rows_concurrent() || e->a.B > 65536 || e->a.node_cap > 65536)) n_subs = 1;
+        if (graphable && n_subs > 1) {
+            const int per = (e->a.B + n_subs - 1) / n_subs;
+            if (!e->sub_fork) AZD_HIP(hipEventCreateWithFlags(&e->sub_fork, hipEventDisableTiming));
+            for (int i = 0; i < n_subs; ++i) {
+                if (!e->sub_stream[i]) AZD_HIP(hipStreamCreateWithFlags(&e->sub_stream[i], hipStreamNonBlocking));
+                if (!e->sub_join[i]) AZD_HIP(hipEventCreateWithFlags(&e->sub_join[i], hipEventDisableTiming));
+            }
+            if (e->sub_graph_n != n_subs || memcmp(&e->call_graph_tol, &t, sizeof(t)) != 0 || e->call_graph_layout != e->ev->layout_version) {
+                for (int i = 0; i < azd_engine::MAX_SUBS; ++i)
+                    if (e->sub_graph[i]) {
+                        (void)hipGraphExecDestroy(e->sub_graph[i]);
+                        e->sub_graph[i] = nullptr;
+                    }
+                e->sub_graph_n = 0;
+                for (int i = 0; i < n_subs; ++i) {
+                    azd::Arenas as = e->a;
+                    as.t0 = i * per;
+                    as.tn = e->a.B - as.t0 < per ? e->a.B - as.t0 : per;
+                    if (as.tn <= 0) continue;
+                    hipGraph_t g = nullptr;
+                    AZD_HIP(hipStreamBeginCapture(e->sub_stream[i], hipStreamCaptureModeThreadLocal));
+                    azd::launch_rollout(as, t, e->sub_stream[i]);
+                    st = e->ev->write_predictions_rows(as.t0, as.tn, e->a.state_vecs, e->a.state_vecs16, e->a.S16, e->a.h_theta, e->sub_stream[i]);
+                    azd::launch_add_actions(as, 0, e->sub_stream[i]);
+                    azd::launch_log_candidates(as, e->d_log_key, e->d_call_ctr + i, e->sub_stream[i]);
+                    hipError_t he = hipStreamEndCapture(e->sub_stream[i], &g);
+                    if (st) {
+                        if (g) (void)hipGraphDestroy(g);
+                        return st;
+                    }
+                    if (he != hipSuccess) return azd::hip_fail(he, "hipStreamEndCapture");
+                    he = hipGraphInstantiate(&e->sub_graph[i], g, nullptr, nullptr, 0);
+                    (void)hipGraphDestroy(g);
+                    if (he != hipSuccess) return azd::hip_fail(he, "hipGraphInstantiate");
+                }
+                e->sub_graph_n = n_subs;
+                e->call_graph_tol = t;
+                e->call_graph_layout = e->ev->layout_version;
+                if (e->call_graph) { // (the single-stream graph was captured for another tol table or layout)
+                    (void)hipGraphExecDestroy(e->call_graph);
+                    e->call_graph = nullptr;
+                }
+            }
+            int left = n_calls;
+            while (left > 0) {
+                const int k = left < e->log_calls ? left : e->log_calls;
+                if (!e->log_clean) {
+                    AZD_HIP(hipMemsetAsync(e->d_log_key, 0xFF, (size_t)e->log_calls * sizeof(unsigned long long), e->stream));
+                    e->log_clean = true;
+                }
+                AZD_HIP(hipMemsetAsync(e->d_call_ctr, 0, sizeof(uint32_t) * azd_engine::MAX_SUBS, e->stream));
+                AZD_HIP(hipEventRecord(e->sub_fork, e->stream));
+                for (int i = 0; i < n_subs; ++i)
+                    if (e->sub_graph[i]) AZD_HIP(hipStreamWaitEvent(e->sub_stream[i], e->sub_fork, 0));
+                for (int c = 0; c < k; ++c)
+                    for (int i = 0; i < n_subs; ++i)
+                        if (e->sub_graph[i]) AZD_HIP(hipGraphLaunch(e->sub_graph[i], e->sub_stream[i]));
+                for (int i = 0; i < n_subs; ++i)
+                    if (e->sub_graph[i]) {
+                        AZD_HIP(hipEventRecord(e->sub_join[i], e->sub_stream[i]));
+                        AZD_HIP(hipStreamWaitEvent(e->stream, e->sub_join[i], 0));
+                    }
+                azd::launch_argmin_log(e->a, k, e->d_log_key, e->stream); // replays the k calls and leaves the log clean
+                left -= k;
+            }
+            e->ev->calls += (uint64_t)n_calls;
+            e->step_form = AZD_STEP_PER_CALL_GRAPH;
+        } else if (graphable) {
+            if (!e->call_graph || e->sub_graph_n != 0 || memcmp(&e->call_graph_tol, &t, sizeof(t)) != 0 || e->call_graph_layout != e->ev->layout_version) {
+                e->sub_graph_n = 0; // (the sub-population graphs, if any, belong to another tol table or layout from here on)
                 if (e->call_graph) (void)hipGraphExecDestroy(e->call_graph);
                 e->call_graph = nullptr;
                 hipGraph_t g = nullptr;

@@ -135,6 +135,7 @@ struct Arenas {
     ArgminRec *argmin;
     StatusRec *status;
     int n, A, S, KW, B;
+    int t0, tn;             // launch-per-phase kernels over a SUB-population: agents t0 .. t0 + tn - 1 (tn = 0: all B); see engine.hip
     float eval_slope;       // squish slope 1/(C_UPPER - C_LOWER), 04-c21-tree.rs:58-74
     double lam_lo, lam_hi;  // c21: initial bracket of the lambda_1 multisection (c21_host.cpp:c21_lambda_bracket)
     // ---- Ramsey space (space_ramsey.inc); unused (null / 0) for c21
@@ -282,6 +283,10 @@ void launch_init_roots(const Arenas &a, const uint8_t *d_parents, const uint64_t
 void launch_add_actions(const Arenas &a, int root_mode, void *stream);
 void launch_rollout(const Arenas &a, const TolTable &tol, void *stream);
 void launch_argmin(const Arenas &a, int init_mode, void *stream);
+// launch-per-phase form over sub-populations on streams of their own (engine.hip): the candidates of agents a.t0 .. a.t0 + a.tn - 1
+// since their last inspection go into log_key[*call_ctr] (atomic min), the counter is bumped; replayed by launch_argmin_log
+void launch_log_candidates(const Arenas &a, unsigned long long *log_key, uint32_t *call_ctr, void *stream);
+void launch_argmin_log(const Arenas &a, int n_calls, unsigned long long *log_key, void *stream);
 void launch_observe(const Arenas &a, uint32_t n_obs_tol, void *stream);
 bool async_plan(const Arenas &a, const FusedEval &ev, uint32_t *dyn_stride, size_t *dyn_bytes, const char **why = nullptr);
 void launch_async(const Arenas &a, const PersistArgs *d_args, const StepLaunch &sl,
@@ -308,6 +313,7 @@ void dense_launch_init_roots(const Arenas &a, const uint8_t *d_adj, const uint64
 void dense_launch_add_actions(const Arenas &a, int root_mode, void *stream);
 void dense_launch_rollout(const Arenas &a, const TolTable &tol, void *stream);
 void dense_launch_argmin(const Arenas &a, int init_mode, void *stream);
+void dense_launch_argmin_log(const Arenas &a, int n_calls, unsigned long long *log_key, void *stream);
 void dense_launch_observe(const Arenas &a, uint32_t n_obs_tol, void *stream);
 void launch_persist(const Arenas &a, const PersistArgs *d_args, const StepLaunch &sl,
                     uint32_t *log_node, uint32_t dyn_stride, size_t dyn_bytes, void *stream);
@@ -327,6 +333,7 @@ void ramsey_launch_init_roots(const Arenas &a, const uint8_t *d_colors, const ui
 void ramsey_launch_add_actions(const Arenas &a, int root_mode, void *stream);
 void ramsey_launch_rollout(const Arenas &a, const TolTable &tol, void *stream);
 void ramsey_launch_argmin(const Arenas &a, int init_mode, void *stream);
+void ramsey_launch_argmin_log(const Arenas &a, int n_calls, unsigned long long *log_key, void *stream);
 void ramsey_launch_observe(const Arenas &a, uint32_t n_obs_tol, void *stream);
 void ramsey_launch_modify_roots(const Arenas &a, uint64_t seed, uint64_t epoch, uint64_t first_agent, int kmin, int kmax,
                                 uint8_t *d_colors, uint64_t *d_perm, void *stream);

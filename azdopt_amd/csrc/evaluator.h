@@ -45,6 +45,13 @@ struct azd_evaluator {
         return write_predictions_dev(batch, d_s, d_p, st);
     }
     virtual int input16_pitch() { return 0; }
+    // The rows row0 .. row0 + count - 1 of a batch whose buffers start at d_s / d_s16 / d_p.  rows_concurrent(): calls on DISJOINT
+    // row ranges may run at the same time on different streams (the engine's launch-per-phase form over sub-populations).
+    virtual int write_predictions_rows(int row0, int count, const float *d_s, const uint16_t *d_s16, int pitch16, float *d_p, hipStream_t st) {
+        return write_predictions_dev16(count, d_s + (size_t)row0 * state_dim, d_s16 ? d_s16 + (size_t)row0 * pitch16 : nullptr, pitch16,
+                                       d_p + (size_t)row0 * action_dim, st);
+    }
+    virtual bool rows_concurrent() { return false; }
     // description for the persistent step (evaluator inside the kernel); false = not fusable
     virtual bool fused_desc(azd::FusedEval *) { return false; }
     // write_predictions_dev(batch) launches the same kernels with the same arguments on every call and allocates nothing

@@ -517,19 +517,20 @@ struct MlpEvaluator : azd_evaluator {
     }
     // The bf16 forward on the LDS-DMA GEMM (gemm_bf16_glds.inc): x16 = the input rows as bf16 with pitch kp[0] (the producer's own
     // copy: azd_evaluator::write_predictions_dev16), or null: converted here from the f32 rows.  Same sums as k_gemm_bf16.
-    int forward16(int batch, const float *d_s, const uint16_t *x16, float *d_p, hipStream_t st) {
+    // act_row0: the rows of the activation buffers this call may use (write_predictions_rows: disjoint ranges run concurrently)
+    int forward16(int batch, const float *d_s, const uint16_t *x16, float *d_p, hipStream_t st, int act_row0 = 0) {
         if (!x16) {
             const int per = kp[0] / 4;
             const size_t n = (size_t)batch * per;
-            k_rows_to_bf16<<<(unsigned)((n + 255) / 256), 256, 0, st>>>(d_s, dims[0], batch, dims[0], d_act16[0], kp[0]);
-            x16 = d_act16[0];
+            k_rows_to_bf16<<<(unsigned)((n + 255) / 256), 256, 0, st>>>(d_s, dims[0], batch, dims[0], d_act16[0] + (size_t)act_row0 * kp[0], kp[0]);
+            x16 = d_act16[0] + (size_t)act_row0 * kp[0];
         }
         for (int l = 0; l < L; ++l) {
             const bool last = l == L - 1;
-            void *y = last ? (void *)d_p : (void *)d_act16[(size_t)l + 1];
+            void *y = last ? (void *)d_p : (void *)(d_act16[(size_t)l + 1] + (size_t)act_row0 * kp[(size_t)l + 1]);
             launch_gemm16(st, x16, kp[(size_t)l], d_w16p + wp_off[(size_t)l], kp[(size_t)l], y, last ? dims[(size_t)L] : kp[(size_t)l + 1], batch,
                           dims[(size_t)l + 1], kp[(size_t)l], last ? final_act : AZD_ACT_RELU, last ? 0 : 1, d_params + b_off[(size_t)l], n_cus);
-            x16 = d_act16[(size_t)(last ? l : l + 1)];
+            if (!last) x16 = d_act16[(size_t)l + 1] + (size_t)act_row0 * kp[(size_t)l + 1];
         }
         AZD_HIP(hipGetLastError());
         return AZD_OK;
@@ -596,6 +597,13 @@ struct MlpEvaluator : azd_evaluator {
         return forward16(batch, d_s, d_s16, d_p, st);
     }
     int input16_pitch() override { return (bf16 && d_w16p) ? kp[0] : 0; }
+    int write_predictions_rows(int row0, int count, const float *d_s, const uint16_t *d_s16, int pitch16, float *d_p, hipStream_t st) override {
+        if (!rows_concurrent() || row0 + count > cap_batch) return azd_evaluator::write_predictions_rows(row0, count, d_s, d_s16, pitch16, d_p, st);
+        AZD_HIP(hipSetDevice(device));
+        const uint16_t *x16 = (d_s16 && pitch16 == kp[0]) ? d_s16 + (size_t)row0 * pitch16 : nullptr;
+        return forward16(count, d_s + (size_t)row0 * state_dim, x16, d_p + (size_t)row0 * action_dim, st, row0);
+    }
+    bool rows_concurrent() override { return bf16 && d_w16p && !getenv("AZD_GEMM_OLD"); }
 
     // dfdx.rs:86-131
     int update_model_dev(int batch, const float *d_s, const float *d_o, const float *d_w, float *loss, hipStream_t st) override {

@@ -30,11 +30,11 @@ static void l_init_roots(const Arenas &a, const uint8_t *p, const uint64_t *m, h
 }
 template <class SP>
 static void l_add_actions(const Arenas &a, int root_mode, hipStream_t st) {
-    k_add_actions<SP><<<dim3(a.B), dim3(64), SP::dyn_bytes(a), st>>>(a, root_mode);
+    k_add_actions<SP><<<dim3(a.tn ? a.tn : a.B), dim3(64), SP::dyn_bytes(a), st>>>(a, root_mode);
 }
 template <class SP>
 static void l_rollout(const Arenas &a, const TolTable &tol, hipStream_t st) {
-    k_rollout<SP><<<dim3(a.B), dim3(64), SP::dyn_bytes(a), st>>>(a, tol);
+    k_rollout<SP><<<dim3(a.tn ? a.tn : a.B), dim3(64), SP::dyn_bytes(a), st>>>(a, tol);
 }
 template <class SP>
 static void l_argmin(const Arenas &a, int init_mode, hipStream_t st) {
@@ -73,6 +73,13 @@ void ramsey_launch_add_actions(const Arenas &a, int root_mode, void *stream) {
 }
 void ramsey_launch_rollout(const Arenas &a, const TolTable &tol, void *stream) {
     DISPATCH_RKW(a, l_rollout, a, tol, (hipStream_t)stream);
+}
+template <class SP>
+static void l_argmin_log(const Arenas &a, int n_calls, unsigned long long *log_key, hipStream_t st) {
+    k_argmin_log1<SP><<<dim3(1), dim3(64), SP::dyn_bytes(a), st>>>(a, n_calls, log_key, nullptr);
+}
+void ramsey_launch_argmin_log(const Arenas &a, int n_calls, unsigned long long *log_key, void *stream) {
+    DISPATCH_RKW(a, l_argmin_log, a, n_calls, log_key, (hipStream_t)stream);
 }
 void ramsey_launch_argmin(const Arenas &a, int init_mode, void *stream) {
     DISPATCH_RKW(a, l_argmin, a, init_mode, (hipStream_t)stream);

@@ -217,11 +217,11 @@ static void l_init_roots(const Arenas &a, const uint8_t *p, const uint64_t *m, h
 }
 template <class SP>
 static void l_add_actions(const Arenas &a, int root_mode, hipStream_t st) {
-    k_add_actions<SP><<<dim3(a.B), dim3(64), SP::dyn_bytes(a), st>>>(a, root_mode);
+    k_add_actions<SP><<<dim3(a.tn ? a.tn : a.B), dim3(64), SP::dyn_bytes(a), st>>>(a, root_mode);
 }
 template <class SP>
 static void l_rollout(const Arenas &a, const TolTable &tol, hipStream_t st) {
-    k_rollout<SP><<<dim3(a.B), dim3(64), SP::dyn_bytes(a), st>>>(a, tol);
+    k_rollout<SP><<<dim3(a.tn ? a.tn : a.B), dim3(64), SP::dyn_bytes(a), st>>>(a, tol);
 }
 template <class SP>
 static void l_argmin(const Arenas &a, int init_mode, hipStream_t st) {
@@ -251,6 +251,18 @@ void launch_argmin(const Arenas &a, int init_mode, void *stream) {
     if (a.space == SPACE_RAMSEY) return ramsey_launch_argmin(a, init_mode, stream);
     if (a.space == SPACE_DENSE) return dense_launch_argmin(a, init_mode, stream);
     DISPATCH_KW(a, l_argmin, a, init_mode, (hipStream_t)stream);
+}
+template <class SP>
+static void l_argmin_log(const Arenas &a, int n_calls, unsigned long long *log_key, hipStream_t st) {
+    k_argmin_log1<SP><<<dim3(1), dim3(64), SP::dyn_bytes(a), st>>>(a, n_calls, log_key, nullptr);
+}
+void launch_argmin_log(const Arenas &a, int n_calls, unsigned long long *log_key, void *stream) {
+    if (a.space == SPACE_RAMSEY) return ramsey_launch_argmin_log(a, n_calls, log_key, stream);
+    if (a.space == SPACE_DENSE) return dense_launch_argmin_log(a, n_calls, log_key, stream);
+    DISPATCH_KW(a, l_argmin_log, a, n_calls, log_key, (hipStream_t)stream);
+}
+void launch_log_candidates(const Arenas &a, unsigned long long *log_key, uint32_t *call_ctr, void *stream) {
+    k_log_candidates<<<dim3(1), dim3(1024), 0, (hipStream_t)stream>>>(a, log_key, call_ctr);
 }
 void launch_observe(const Arenas &a, uint32_t n_obs_tol, void *stream) {
     if (a.space == SPACE_RAMSEY) return ramsey_launch_observe(a, n_obs_tol, stream);

@@ -52,9 +52,11 @@ WORKLOADS = {
     "r44": dict(kind="ramsey", n=17, sizes=[4, 4], agents=8192, hidden=(256, 256, 256),
                 tol=([200, 200, 100, 100, 50, 50, 25, 25], 10),
                 caps=dict(prediction_capacity=57344), name="Ramsey R(4,4) N=17"),
-    # BASELINE configs[4]: the build-defined dense-graph space (oracle/dense_graph.inc), N = 50, G(50, 0.1) roots with up to
-    # 128 modifiable edge slots, 512-wide model; runs one launch per phase, replayed from a hipGraph
-    "dense50": dict(kind="dense", n=50, p=0.1, agents=8192, hidden=(512, 512, 512), tol=([200, 50, 50], 25),
+    # BASELINE configs[4]: the build-defined dense-graph space (oracle/dense_graph.inc), N = 50, G(50, 0.1) roots, 512-wide
+    # model; one launch per phase, replayed from hipGraphs over four sub-populations.  max_slots = the most modifiable edge slots
+    # a root brings (= predictions a node holds): 128 keeps a tree's prediction arena at 2 MB for 8192 agents per GPU; the
+    # drivers' image E // 2 = 612 is built and tested (tests/test_gpu_dense.py) and measured with --max-slots 612 at fewer agents
+    "dense50": dict(kind="dense", n=50, p=0.1, agents=8192, hidden=(512, 512, 512), tol=([200, 50, 50], 25), max_slots=128,
                     caps=dict(prediction_capacity=131072), name="dense graphs N=50"),
 }
 # BASELINE.json configs[0..3] as presets: (workload, agents per GPU, evaluator storage)
@@ -70,7 +72,7 @@ HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 
 def make_space(az, wl):
     if wl["kind"] == "dense":
-        return az.DenseGraphSpace(wl["n"], wl["p"])
+        return az.DenseGraphSpace(wl["n"], wl["p"], max_slots=wl.get("max_slots", 128))
     if wl["kind"] == "ramsey":
         return az.RamseySpaceNoEdgeRecolor(wl["n"], wl["sizes"])
     return az.ROTModifyParentsOnce(wl["n"])
@@ -167,6 +169,8 @@ def main():
                          "C 8192 agents/GPU bf16 (65536 at --gpus 8), D Ramsey r44 8192 agents/GPU")
     ap.add_argument("--workload", choices=sorted(WORKLOADS), default=None)
     ap.add_argument("--agents", type=int, default=0, help="agents per GPU (default: the workload's)")
+    ap.add_argument("--max-slots", type=int, default=0, help="dense-graph workload: modifiable edge slots a root may bring (default 128; E // 2 = 612 is the drivers' image)")
+    ap.add_argument("--prediction-capacity", type=int, default=0, help="override the workload's per-tree prediction arena")
     ap.add_argument("--mlp-dtype", choices=["f32", "bf16"], default=None,
                     help="evaluator weight/activation storage for inference (bf16 = BASELINE configs[2]; f32 accumulate either way)")
     args = ap.parse_args()
@@ -176,6 +180,10 @@ def main():
         agents = WORKLOADS[wl_name]["agents"]
     wl = dict(WORKLOADS[wl_name])
     wl["agents"] = args.agents if args.agents > 0 else agents
+    if args.max_slots > 0:
+        wl["max_slots"] = args.max_slots
+    if args.prediction_capacity > 0:
+        wl["caps"] = dict(wl["caps"], prediction_capacity=args.prediction_capacity)
     mlp_dtype = args.mlp_dtype or dtype
     AGENTS_PER_GPU, TOL, HIDDEN = wl["agents"], wl["tol"], tuple(wl["hidden"])
 
@@ -227,10 +235,7 @@ def main():
     def epoch_boundary():
         nonlocal epoch, boundaries
         losses.append(sopt.par_update_model(N_OBS_TOL))  # N > 1: all-gather of the training triple, then the identical step
-        if wl["kind"] == "dense":  # no device root policy for this space: `modify_root` = fresh seeded roots from the host
-            sopt.par_reset_trees(space.generate_roots(SEED, B, first_agent=sopt.plan.first_agent, epoch=epoch + 1))
-        else:
-            sopt.par_reset_trees_policy(SEED, epoch)     # modify_root policy + reset on the device
+        sopt.par_reset_trees_policy(SEED, epoch)     # modify_root policy + reset on the device (every space)
         epoch += 1
         boundaries += 1
 
@@ -349,8 +354,10 @@ def main():
             "metric": "node_expansions_per_s", "value": exp_total / dt_max, "unit": "expansions/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * dt_max / args.steps,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": mlp_dtype, "data": "synthetic",
-            "config": {"workload": "%s tree search, %d agents/GPU, %s MLP %s, tol %s/%d; timed: %s"
-                                   % (wl["name"], AGENTS_PER_GPU, "fp32" if mlp_dtype == "f32" else "bf16-storage", dims_txt,
+            "config": {"workload": "%s%s tree search, %d agents/GPU, %s MLP %s, tol %s/%d; timed: %s"
+                                   % (wl["name"], (" (roots with %d..%d of the E = %d edge slots modifiable; the engine holds up to %d, E // 2 = %d is the drivers' image)"
+                                                   % (space.default_permitted_range() + (space.E, space.MAX_SLOTS, space.E // 2))) if wl["kind"] == "dense" else "",
+                                      AGENTS_PER_GPU, "fp32" if mlp_dtype == "f32" else "bf16-storage", dims_txt,
                                       str(TOL[0]).replace(" ", ""), TOL[1], window),
                        "baseline_config": args.config or ("B" if (wl_name, AGENTS_PER_GPU, mlp_dtype) == CONFIGS["B"] else None),
                        "agents_total": B_total, "parallelism": f"agents sharded x{world}"},

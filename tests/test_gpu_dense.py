@@ -158,15 +158,19 @@ def test_dense_n50_with_the_512_wide_bf16_model(az, orc):
     assert np.isfinite(loss) and loss >= 0
 
 
-def test_hipgraph_replay_of_the_per_call_form_equals_launch_by_launch(az):
+def test_hipgraph_replay_of_the_per_call_form_equals_launch_by_launch(az, monkeypatch):
     """with the MLP evaluator the launches of a call (roll-out, GEMMs, add_actions, argmin) are captured once in a
-    hipGraph and replayed per call: same trees, counters, argmin and improvement count as launching them one by one"""
+    hipGraph and replayed per call: same trees, counters, argmin and improvement count as launching them one by one.
+    Third run: the population cut into three sub-populations, each with a stream and a graph of its own, running their calls
+    independently (the per-call argmin replayed from the candidate log): the form large populations take."""
     n, B, seed = 20, 40, 6
     tol = ([50, 20, 10], 5)
     space = az.DenseGraphSpace(n, 0.2)
     roots = space.generate_roots(seed, B)
     runs = []
-    for graph in (True, False):
+    for graph in (True, False, "subs"):
+        if graph == "subs":
+            monkeypatch.setenv("AZD_PER_CALL_STREAMS", "3")
         model = az.ActionModel(B, space.STATE_DIM, space.ACTION_DIM, hidden=(128, 128), seed=seed, dtype="bf16")
         o = az.NablaOptimizer.par_new(space, roots, model, B)
         if graph:
@@ -177,6 +181,17 @@ def test_hipgraph_replay_of_the_per_call_form_equals_launch_by_launch(az):
             imp = sum(o.par_roll_out_episodes(tol, n_calls=1) for _ in range(90))
             assert o.step_form()[0] == "per_call"
         runs.append((o, imp))
+    monkeypatch.delenv("AZD_PER_CALL_STREAMS")
+    (o2, i2) = runs.pop()
+    assert i2 == runs[0][1]
+    c0, c2 = runs[0][0].counters(), o2.counters()
+    for k in MAIN_CTRS:
+        assert c0[k] == c2[k], k
+    for i in range(B):
+        assert_tree_equal(runs[0][0].get_tree(i), o2.get_tree(i), f"sub-populations, agent {i}")
+    a0, a2 = runs[0][0].argmin_data(), o2.argmin_data()
+    assert a0.eval == a2.eval and a0.agent == a2.agent and a0.node == a2.node
+    assert np.array_equal(runs[0][0].state_vecs(), o2.state_vecs())
     (o0, i0), (o1, i1) = runs
     assert i0 == i1
     c0, c1 = o0.counters(), o1.counters()
