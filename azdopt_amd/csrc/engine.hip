@@ -1323,6 +1323,10 @@ int azd_engine_par_update_model_sharded(azd_engine *e, uint32_t n_obs_tol, void 
         AZD_HIP(hipMalloc(&e->d_pool, (ns + 2 * na) * sizeof(float)));
         e->pool_rows = rows;
     }
+    if (rows > e->pool_rows || rows > (size_t)INT32_MAX) { // (the pooled buffers hold `pool_rows` rows: sized just above)
+        azd::g_last_error = "pooled batch does not fit its buffers";
+        return AZD_ERR_CAPACITY;
+    }
     float *g_sv = e->d_pool, *g_obs = g_sv + ns, *g_w = g_obs + na;
     azd::launch_observe(a, n_obs_tol, e->stream); // :262-278 on this rank's trees
     AZD_HIP(hipGetLastError());
@@ -1334,6 +1338,7 @@ int azd_engine_par_update_model_sharded(azd_engine *e, uint32_t n_obs_tol, void 
     for (int i = 0; i < 3; ++i) {
         rc = api.allGather(src[i], dst[i], cnt[i], NCCL_FLOAT32, nccl_comm, e->stream);
         if (rc != 0) {
+            (void)hipStreamSynchronize(e->stream); // k_observe and the collectives already queued: nothing of this call is left in flight
             azd::g_last_error = std::string("ncclAllGather: ") + (api.errorString ? api.errorString(rc) : "failed");
             return AZD_ERR_HIP;
         }

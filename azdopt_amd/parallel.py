@@ -118,6 +118,9 @@ class EngineShard:
     def expansions(self):
         return self.opt.counters()["EXPANSIONS"]
 
+    def params_bytes(self):
+        return self.model.get_params().tobytes()
+
 
 class ShardedOptimizer:
     """NablaOptimizer<Space, M, P> (optimizer/mod.rs) over a population sharded across the ranks of a
@@ -158,11 +161,44 @@ class ShardedOptimizer:
         return self.shard.roll_out(n_as_tol, n_calls)
 
     def par_update_model(self, n_obs_tol):
-        """optimizer/mod.rs:249-281 over the pooled rows of all ranks, identical on every rank."""
+        """optimizer/mod.rs:249-281 over the pooled rows of all ranks, identical on every rank.  `native_comm` set
+        (use_native_exchange): the one C-ABI call azd_engine_par_update_model_sharded does observe -> ncclAllGather x 3 ->
+        optimiser step on the engine's own stream instead of torch.distributed."""
         if self.dist is None:
             return self.shard.update_local(n_obs_tol)
-        pooled = allgather_training_triple(self.dist, self.torch, self.shard.triple(n_obs_tol), self.plan.world_size)
+        import time
+        if getattr(self, "native_comm", None) is not None:
+            t0 = time.perf_counter()
+            loss = self.shard.opt.par_update_model_sharded(n_obs_tol, self.native_comm)
+            self.exchange_ms = getattr(self, "exchange_ms", 0.0) + 1e3 * (time.perf_counter() - t0)  # (all-gather + step: one call)
+            self.exchanges = getattr(self, "exchanges", 0) + 1
+            return loss
+        local = self.shard.triple(n_obs_tol)
+        sync = getattr(self.torch.cuda, "synchronize", None) if str(self.coll_device).startswith("cuda") else None
+        if sync:
+            sync()
+        t0 = time.perf_counter()
+        pooled = allgather_training_triple(self.dist, self.torch, local, self.plan.world_size)
+        if sync:
+            sync()
+        self.exchange_ms = getattr(self, "exchange_ms", 0.0) + 1e3 * (time.perf_counter() - t0)  # the all-gather alone
+        self.exchanges = getattr(self, "exchanges", 0) + 1
         return self.shard.update_pooled(self.plan.total_agents, pooled)
+
+    def use_native_exchange(self, nccl_comm):
+        """epoch exchange through azd_engine_par_update_model_sharded with this ncclComm_t (raw handle) from now on"""
+        self.native_comm = nccl_comm
+
+    def replicas_identical(self):
+        """every rank took the identical optimiser step: all-gather of a 64-bit hash of this rank's parameters"""
+        import hashlib
+        h = int.from_bytes(hashlib.blake2b(self.shard.params_bytes(), digest_size=8).digest(), "little") >> 1
+        if self.dist is None:
+            return True
+        mine = self.torch.tensor([h], dtype=self.torch.int64, device=self.coll_device)
+        allv = self.torch.empty(self.plan.world_size, dtype=self.torch.int64, device=self.coll_device)
+        self.dist.all_gather_into_tensor(allv, mine)
+        return bool((allv == allv[0]).all().item())
 
     def par_reset_trees_policy(self, seed, epoch, kmin=None, kmax=None):
         """optimizer/mod.rs:284-360 with the drivers' modify_root policy on the device; per rank, no collective"""

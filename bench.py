@@ -169,6 +169,9 @@ def main():
                          "C 8192 agents/GPU bf16 (65536 at --gpus 8), D Ramsey r44 8192 agents/GPU")
     ap.add_argument("--workload", choices=sorted(WORKLOADS), default=None)
     ap.add_argument("--agents", type=int, default=0, help="agents per GPU (default: the workload's)")
+    ap.add_argument("--exchange", choices=["torch", "native"], default="torch",
+                    help="N > 1: the epoch exchange through torch.distributed (all_gather_into_tensor on the nccl = RCCL backend) or through "
+                         "the C ABI's azd_engine_par_update_model_sharded with an ncclComm_t of its own (ncclAllGather on the engine's stream)")
     ap.add_argument("--max-slots", type=int, default=0, help="dense-graph workload: modifiable edge slots a root may bring (default 128; E // 2 = 612 is the drivers' image)")
     ap.add_argument("--prediction-capacity", type=int, default=0, help="override the workload's per-tree prediction arena")
     ap.add_argument("--mlp-dtype", choices=["f32", "bf16"], default=None,
@@ -218,6 +221,34 @@ def main():
         AGENTS_PER_GPU, dist=dist if world > 1 else None, torch=torch, seed=SEED, device_index=local_rank, rank=rank,
         world_size=world, stage_on_cpu=rehearse, async_step=not (args.barrier_step or args.step == "barrier"),
         pool_step={"pool": True, "async": False, "barrier": False}.get(args.step), **wl["caps"])
+    native_comm = None
+    if world > 1 and args.exchange == "native" and not rehearse:
+        # an RCCL communicator of the bench's own for the native entry point: rank 0 draws the id, torch.distributed carries it
+        import ctypes as C
+
+        class _Uid(C.Structure):
+            _fields_ = [("internal", C.c_char * 128)]
+
+        rccl = None
+        for name in ("librccl.so.1", "/opt/rocm/lib/librccl.so.1", "librccl.so"):
+            try:
+                rccl = C.CDLL(name, mode=C.RTLD_GLOBAL)
+                break
+            except OSError:
+                continue
+        if rccl is None:
+            raise SystemExit("--exchange native: librccl.so not found")
+        uid = _Uid()
+        if rank == 0 and rccl.ncclGetUniqueId(C.byref(uid)) != 0:
+            raise SystemExit("ncclGetUniqueId failed")
+        box = [bytes(uid.internal)]
+        dist.broadcast_object_list(box, src=0)
+        C.memmove(C.byref(uid), box[0], 128)
+        native_comm = C.c_void_p()
+        rccl.ncclCommInitRank.argtypes = [C.POINTER(C.c_void_p), C.c_int, _Uid, C.c_int]
+        if rccl.ncclCommInitRank(C.byref(native_comm), world, uid, rank) != 0:
+            raise SystemExit("ncclCommInitRank failed on rank %d" % rank)
+        sopt.use_native_exchange(native_comm)
     opt = sopt.shard.opt  # this rank's NablaOptimizer (counters, timing)
     B, B_total = sopt.plan.local_agents, sopt.plan.total_agents
     coll_dev = sopt.coll_device
@@ -287,14 +318,22 @@ def main():
         raise SystemExit("bench: %d agents stopped on a full arena; the rate would count fewer working agents" % c1["FAILED"])
 
     exp_local = c1["EXPANSIONS"] - c0["EXPANSIONS"]
+    per_rank_rates = [exp_local / dt]
     if world > 1:
         t = torch.tensor([dt, float(exp_local)], dtype=torch.float64, device=coll_dev)
         tmax = t.clone()
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dist.all_reduce(t, op=dist.ReduceOp.SUM)
         dt_max, exp_total = float(tmax[0]), float(t[1])
+        rates = torch.empty(world, dtype=torch.float64, device=coll_dev)
+        dist.all_gather_into_tensor(rates, torch.tensor([exp_local / dt], dtype=torch.float64, device=coll_dev))
+        per_rank_rates = [float(x) for x in rates.cpu()]
     else:
         dt_max, exp_total = dt, float(exp_local)
+    # every rank must hold the same parameters after the pooled optimiser steps (64-bit hash, all-gathered); outside the timed region
+    replicas_ok = sopt.replicas_identical() if mlp_dtype else True
+    if not replicas_ok:
+        raise SystemExit("bench: the ranks' model replicas differ after the epoch exchange")
     best_eval, best_cost = sopt.global_argmin()
     if per_call:  # the roofline figures below describe the extra launch-by-launch calls, not the graph replays
         exp_for_roofline = opt.counters()["EXPANSIONS"] - c1["EXPANSIONS"]
@@ -361,6 +400,14 @@ def main():
                                       str(TOL[0]).replace(" ", ""), TOL[1], window),
                        "baseline_config": args.config or ("B" if (wl_name, AGENTS_PER_GPU, mlp_dtype) == CONFIGS["B"] else None),
                        "agents_total": B_total, "parallelism": f"agents sharded x{world}"},
+            "world": world, "per_rank_expansions_per_s": per_rank_rates, "replicas_identical": replicas_ok,
+            "epoch_exchange": None if world == 1 else {
+                "via": "azd_engine_par_update_model_sharded (ncclAllGather x 3 on the engine's stream + the optimiser step)" if native_comm is not None
+                       else ("gloo over host staging (rehearsal)" if rehearse else "torch.distributed all_gather_into_tensor x 3 (backend nccl = RCCL)"),
+                "count": getattr(sopt, "exchanges", 0),
+                "ms_each": (getattr(sopt, "exchange_ms", 0.0) / max(1, getattr(sopt, "exchanges", 0))),
+                "bytes_per_rank_each": 4 * B * (space.STATE_DIM + 2 * space.ACTION_DIM),
+                "note": "native: one call = all-gather + optimiser step; torch: the all-gather alone"},
             "step_form": form, "step_form_reason": form_why, "pool_split": list(opt.pool_split()) if form == "pool" else None,
             "epoch_boundary_in_timed_region": n_bound > 0, "epoch_boundaries_in_timed_region": n_bound,
             "best_cost_found": best_cost, "best_eval": best_eval,
