@@ -159,6 +159,7 @@ def lib():
     sig("azd_engine_stream", vp, vp)
     sig("azd_engine_step_form", C.c_int, vp, i32p, C.POINTER(C.c_char_p))
     sig("azd_engine_pool_split", C.c_int, vp, i32p, i32p)
+    sig("azd_engine_pool_utilisation", C.c_int, vp, C.POINTER(C.c_double), C.POINTER(C.c_double))
     sig("azd_debug_probe_xcc", C.c_int, C.c_int, vp, C.c_int)
     sig("azd_debug_hash_stream_via_evaluators", C.c_int, vp, C.c_int)
     sig("azd_debug_probe_math", C.c_int, C.c_int, vp, vp, C.c_int)

@@ -169,6 +169,17 @@ struct azd_engine {
     size_t pool_slot_words = 0;
     int n_cus = 0;
     int pool_eval_wgs = 0, pool_search_wgs = 0; // of the last launch (diagnostics)
+    int pool_search_waves = 0;                  // searching waves of the last launch
+    double pool_util_eval = 0, pool_util_search = 0; // busy share of the two sides in the last completed pool launch
+    // Measured feedback on the split (the fitted constants give the first guess only).  Every pool launch reports how busy its two
+    // sides were (PoolCtl::eval_busy / search_busy over the launch's span): the share of its time an evaluator workgroup spent
+    // on batches, u_e, and the share a searcher wave spent with an agent in hand, u_s.  Across splits u_e falls and u_s rises
+    // with the evaluators' share, and the best split of every workload measured sits where u_e - u_s is +0.00 .. +0.09
+    // (profiles/r03_pool_split.txt: configs A-D, 8192 agents fp32, a 384 x 384 model no sweep had seen), so the next launch
+    // moves the evaluators' share by 100 workgroups per unit of (u_e - u_s - 0.05).
+    struct {
+        int n_eval = 0; // what the next launch takes (0: the first guess)
+    } pool_fb;
     float *d_pool = nullptr;      // pooled training triple of all ranks (azd_engine_par_update_model_sharded)
     size_t pool_rows = 0;
     int step_form = 0;            // AZD_STEP_* chosen by the last par_roll_out_episodes
@@ -221,6 +232,11 @@ struct azd_engine {
 namespace {
 
 using namespace azd;
+
+bool pool_feedback_on() {
+    const char *env = getenv("AZD_POOL_FEEDBACK");
+    return !env || atoi(env) != 0;
+}
 
 int next_pow2(int v) {
     int p = 128;
@@ -930,6 +946,13 @@ int azd_engine_par_roll_out_episodes(azd_engine *e, const uint32_t *tol, int n_t
                 n_eval = n_eval > most ? most : n_eval;
             }
             n_eval = n_eval < 1 ? 1 : n_eval;
+            if (pool_feedback_on() && e->pool_fb.n_eval > 0) { // the split the last launches' busy shares ask for, under the same caps
+                const int fb = e->pool_fb.n_eval;
+                const int want_search = (B + 7) / 8, most = want_search < e->n_cus / 2 ? e->n_cus - want_search : e->n_cus / 2;
+                n_eval = fb > cap ? cap : fb;
+                n_eval = n_eval > most ? most : n_eval;
+                n_eval = n_eval < 1 ? 1 : n_eval;
+            }
             if (const char *env = getenv("AZD_POOL_EVAL_WGS")) n_eval = atoi(env) > 0 ? atoi(env) : n_eval;
         }
         int n_search = e->n_cus - n_eval;
@@ -993,6 +1016,7 @@ int azd_engine_par_roll_out_episodes(azd_engine *e, const uint32_t *tol, int n_t
         pool_blocks = n_eval + n_search;
         e->pool_eval_wgs = n_eval;
         e->pool_search_wgs = n_search;
+        e->pool_search_waves = (n_search - pool.n_express) * 16 + pool.n_express * (int)pool.express_waves;
     }
     if (e->pool_step && fusable && !use_pool) { // the pool step was wanted and cannot run: the next form down
         use_async = !e->barrier_step && azd::async_plan(e->a, fe, &dyn_stride, &dyn_bytes, &why_a);
@@ -1029,6 +1053,7 @@ int azd_engine_par_roll_out_episodes(azd_engine *e, const uint32_t *tol, int n_t
             e->pool_clean = true;
             return AZD_OK;
         };
+        const bool fb_on = use_pool && fe.kind == 3 && pool_feedback_on() && n_calls >= 100 && !getenv("AZD_POOL_EVAL_WGS");
         int left = n_calls;
         while (left > 0) {
             const int k = left < e->log_calls ? left : e->log_calls;
@@ -1066,6 +1091,11 @@ int azd_engine_par_roll_out_episodes(azd_engine *e, const uint32_t *tol, int n_t
                 st = fetch_status(e);
                 if (st) return st;
                 status_fresh = left == 0; // the last launch's status is in, and nothing ran behind it
+                if (e->h_status->pool_ticks > 0 && !e->h_status->pool_abort) {
+                    const double T = (double)e->h_status->pool_ticks;
+                    e->pool_util_eval = e->pool_eval_wgs > 0 ? (double)e->h_status->pool_eval_busy / (T * e->pool_eval_wgs) : 0.0;
+                    e->pool_util_search = e->pool_search_waves > 0 ? (double)e->h_status->pool_search_busy / (T * e->pool_search_waves) : 0.0;
+                }
                 if (e->h_status->pool_abort) {
                     e->pool_clean = false;
                     e->log_clean = false; // (it holds the aborted launch's candidates, which the take-over's replay needs: not cleared here)
@@ -1102,6 +1132,15 @@ int azd_engine_par_roll_out_episodes(azd_engine *e, const uint32_t *tol, int n_t
             e->ev->calls += (uint64_t)k;
         }
         AZD_HIP(hipGetLastError());
+        if (fb_on && use_pool && status_fresh && e->h_status->pool_ticks > 0) { // the launch is over and its busy shares are in
+            const double d = e->pool_util_eval - e->pool_util_search - 0.05;
+            const int cur = e->pool_eval_wgs, lim = cur / 4 > 4 ? cur / 4 : 4;
+            int mv = (int)(100.0 * d + (d >= 0 ? 0.5 : -0.5));
+            mv = mv > lim ? lim : mv < -lim ? -lim : mv;
+            int next = cur + mv;
+            next = next > e->n_cus / 2 ? e->n_cus / 2 : next < 1 ? 1 : next;
+            e->pool_fb.n_eval = next;
+        }
     } else {
         // One call = roll-out, model call, add_actions, argmin: four to eight launches.  With the MLP evaluator (whose
         // launches take no per-call arguments) the sequence is captured once into a hipGraph and replayed per call, so
@@ -1683,6 +1722,12 @@ int azd_engine_timing(azd_engine *e, double *tree_ms, double *evaluator_ms, uint
     return AZD_OK;
 }
 void *azd_engine_stream(azd_engine *e) { return e ? (void *)e->stream : nullptr; }
+int azd_engine_pool_utilisation(azd_engine *e, double *eval_busy, double *search_busy) {
+    if (!e) return AZD_ERR_INVALID_ARGUMENT;
+    if (eval_busy) *eval_busy = e->pool_util_eval;
+    if (search_busy) *search_busy = e->pool_util_search;
+    return AZD_OK;
+}
 int azd_engine_pool_split(azd_engine *e, int *eval_wgs, int *search_wgs) {
     if (!e) return AZD_ERR_INVALID_ARGUMENT;
     if (eval_wgs) *eval_wgs = e->pool_eval_wgs;

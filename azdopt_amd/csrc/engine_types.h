@@ -103,6 +103,7 @@ struct StatusRec { // small device block copied back after every host-visible ca
     unsigned long long expansions; // sum over agents and calls (metric numerator)
     unsigned long long failed;     // agents with a non-zero flag
     unsigned long long pool_abort; // the pool launch before this read-back ended on PoolCtl::abort (k_argmin_log1 copies the flag here)
+    unsigned long long pool_eval_busy, pool_search_busy, pool_ticks, pool_pad; // PoolCtl's busy sums and t_last - t_first of that launch
 };
 
 struct Arenas {
@@ -225,6 +226,11 @@ struct PoolCtl {
     } sum_calls[POOL_XCDS], claimed[POOL_XCDS], // calls completed by / agents living on each XCD: their ratio is the mean progress
       done_x[POOL_XCDS],                        // agents of each XCD that are through all their calls (they no longer count for it)
       max_lag[POOL_XCDS];                       // express mode: the largest lag behind the XCD's progress any of its agents has posted with
+    // what the launch's two sides were busy with, in ticks of the 100 MHz wall clock (the host balances the split by them):
+    unsigned long long eval_busy;   // evaluator workgroups: from a batch taken to the batch released, summed over workgroups
+    unsigned long long search_busy; // searcher waves: with an agent in hand (add_actions + calls), summed over waves
+    unsigned long long t_first;     // when the first workgroup started (first writer) ...
+    unsigned long long t_last;      // ... and the last one ended
 };
 struct PendRec { // what a call that ended on a new node leaves for the add_actions that follows the evaluator
     uint32_t pos;

@@ -301,6 +301,12 @@ class NablaOptimizer:
         _lib.check(self._L.azd_engine_pool_split(self._h, C.byref(a), C.byref(b)), "pool_split")
         return a.value, b.value
 
+    def pool_utilisation(self):
+        """(evaluator, searcher) busy shares of the last pool-step launch"""
+        a, b = C.c_double(), C.c_double()
+        _lib.check(self._L.azd_engine_pool_utilisation(self._h, C.byref(a), C.byref(b)), "pool_utilisation")
+        return a.value, b.value
+
     def step_form(self):
         """(form, reason) of the last par_roll_out_episodes: "async" / "barrier" (CU-resident) or "per_call"
         (one launch per phase), and why a faster form was not taken"""

@@ -408,6 +408,9 @@ void *azd_engine_stream(azd_engine *e); /* hipStream_t the engine launches on */
 int azd_engine_step_form(azd_engine *e, int *form, const char **reason);
 /* how the last pool-step launch split the CUs: evaluator / searcher workgroups */
 int azd_engine_pool_split(azd_engine *e, int *eval_wgs, int *search_wgs);
+/* ... and how busy its two sides were: the share of the launch an evaluator workgroup spent on batches, and the share a
+ * searcher wave spent with an agent in hand (the engine moves the split towards equal shares from launch to launch) */
+int azd_engine_pool_utilisation(azd_engine *e, double *eval_busy, double *search_busy);
 /* HW_REG_XCC_ID read by every block of an n_blocks launch (the pool step keeps a tree on the XCD that first took it) */
 int azd_debug_probe_xcc(int device, uint32_t *out, int n_blocks);
 /* Test harness of the pool step: with `on`, a hash-stream evaluator's rows are served by the pool step's EVALUATOR workgroups
