@@ -176,7 +176,7 @@ struct azd_engine {
     // on batches, u_e, and the share a searcher wave spent with an agent in hand, u_s.  Across splits u_e falls and u_s rises
     // with the evaluators' share, and the best split of every workload measured sits where u_e - u_s is +0.00 .. +0.09
     // (profiles/r03_pool_split.txt: configs A-D, 8192 agents fp32, a 384 x 384 model no sweep had seen), so the next launch
-    // moves the evaluators' share by 100 workgroups per unit of (u_e - u_s - 0.05).
+    // moves the evaluators' share by 100 workgroups per unit of (u_e - u_s - target), target 0 .. 0.06 by how crowded the waves are.
     struct {
         int n_eval = 0; // what the next launch takes (0: the first guess)
     } pool_fb;
@@ -1133,7 +1133,11 @@ int azd_engine_par_roll_out_episodes(azd_engine *e, const uint32_t *tol, int n_t
         }
         AZD_HIP(hipGetLastError());
         if (fb_on && use_pool && status_fresh && e->h_status->pool_ticks > 0) { // the launch is over and its busy shares are in
-            const double d = e->pool_util_eval - e->pool_util_search - 0.05;
+            // where the best split sits: at equal shares when the agents hardly outnumber the searching waves (their cycle, not the
+            // chip, sets the pace: configs A, B, the 384 x 384 model), at u_e - u_s = +0.06 when they queue for waves (8192 agents:
+            // a slightly starved evaluator side fills 32-row batches, which cost it a quarter less per row)
+            const double crowd = e->pool_search_waves > 0 ? (double)e->a.B / e->pool_search_waves - 1.5 : 0.0;
+            const double d = e->pool_util_eval - e->pool_util_search - 0.06 * (crowd < 0 ? 0.0 : crowd > 1 ? 1.0 : crowd);
             const int cur = e->pool_eval_wgs, lim = cur / 4 > 4 ? cur / 4 : 4;
             int mv = (int)(100.0 * d + (d >= 0 ? 0.5 : -0.5));
             mv = mv > lim ? lim : mv < -lim ? -lim : mv;
