@@ -1,0 +1,55 @@
+#!/bin/bash
+# Profile refresh of a round (run on the GPU box through gpurun; tools/update_profiles.py copies the summaries to profiles/):
+#   tools/refresh_profiles.sh r03 [part ...]     parts: bench stats tcc sq gemm split curve examples  (default: all)
+export TMPDIR=/tmp
+R=${1:-r03}; shift
+PARTS=${*:-bench stats tcc sq gemm split curve examples}
+O=gpurun_out/final_$R
+mkdir -p $O
+has() { [[ " $PARTS " == *" $1 "* ]]; }
+if has bench; then
+  timeout -k 10 300 python bench.py > $O/bench_default.log 2>&1; tail -1 $O/bench_default.log | cut -c1-140
+  timeout -k 10 200 python bench.py --steps 20 --warmup 5 --no-cpu-baseline > $O/bench_driver20.log 2>&1
+  timeout -k 10 200 python bench.py --no-cpu-baseline --step async > $O/bench_B_async.log 2>&1
+  for cfg in A C D; do timeout -k 10 300 python bench.py --no-cpu-baseline --config $cfg > $O/bench_$cfg.log 2>&1; done
+  timeout -k 10 300 python bench.py --no-cpu-baseline --agents 8192 > $O/bench_B8192.log 2>&1
+  timeout -k 10 400 python bench.py --config E --steps 400 --warmup 50 > $O/bench_E.log 2>&1
+  timeout -k 10 400 python bench.py --config E --steps 200 --warmup 50 --agents 1024 --max-slots 612 --prediction-capacity 524288 --no-cpu-baseline > $O/bench_E612.log 2>&1
+  echo benches done
+fi
+if has stats; then
+  timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof -- python3 bench.py --no-cpu-baseline > $O/prof.log 2>&1
+  timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof20 -- python3 bench.py --no-cpu-baseline --steps 20 --warmup 5 > $O/prof20.log 2>&1
+  timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_E -- python3 bench.py --no-cpu-baseline --config E --steps 200 --warmup 20 > $O/prof_E.log 2>&1
+  echo stats done
+fi
+if has tcc; then
+  timeout -k 10 300 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $O/pmc_fetch -- python3 bench.py --no-cpu-baseline > $O/pmc_fetch.log 2>&1
+  timeout -k 10 300 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $O/pmc_write -- python3 bench.py --no-cpu-baseline > $O/pmc_write.log 2>&1
+  echo tcc done
+fi
+if has sq; then
+  timeout -k 10 300 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_SCA --kernel-trace --output-format csv -d $O/pmc_sq1 -- python3 bench.py --no-cpu-baseline --steps 800 --warmup 800 > $O/pmc_sq1.log 2>&1
+  timeout -k 10 300 rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_SMEM SQ_WAVES SQ_INSTS_VALU_MFMA_MOPS_F32 --kernel-trace --output-format csv -d $O/pmc_sq2 -- python3 bench.py --no-cpu-baseline --steps 800 --warmup 800 > $O/pmc_sq2.log 2>&1
+  echo sq done
+fi
+if has gemm; then
+  { timeout -k 10 200 python tools/time_gemm16.py; for dt in bf16 f32; do timeout -k 10 100 python tools/time_gemm.py $dt 8192; timeout -k 10 100 python tools/time_gemm.py $dt 65536 304,256,256,256,152; timeout -k 10 100 python tools/time_gemm.py $dt 8192 4096,4096,4096; done; AZD_GEMM_OLD=1 timeout -k 10 100 python tools/time_gemm.py bf16 8192; } > $O/gemm.txt 2>&1
+  echo gemm done
+fi
+if has split; then
+  { timeout -k 10 300 python tools/split_util.py B 64 76 88 100 112 124; timeout -k 10 300 python tools/split_util.py X 64 76 88 100 112 124; timeout -k 10 200 python tools/split_util.py C 28 34 40 52 64
+    timeout -k 10 200 python tools/split_util.py D 100 106 112 118 126; timeout -k 10 200 python tools/split_util.py B8 64 72 80 96; timeout -k 10 200 python tools/split_util.py A 33 64 129
+    for c in B X C D B8 A; do timeout -k 10 300 python tools/split_feedback.py $c 10; done; } > $O/pool_split.txt 2>&1
+  echo split done
+fi
+if has curve; then
+  { timeout -k 10 300 python tools/launch_curve.py B 1 5 20 800; AZD_LIB=$PWD/azdopt_amd/libazdopt_amd_r02.so timeout -k 10 300 python tools/launch_curve.py B 1 5 20 800
+    timeout -k 10 300 python tools/launch_curve.py A 1 5 20 800; AZD_LIB=$PWD/azdopt_amd/libazdopt_amd_r02.so timeout -k 10 300 python tools/launch_curve.py A 1 5 20 800; } > $O/curve.txt 2>&1
+  echo curve done
+fi
+if has examples; then
+  { for stride in 1 800; do /usr/bin/time -f "stride $stride: %e s wall" examples/c21_tree 3 800 512 $stride 0 2>&1 | tail -3; done; } > $O/examples.txt 2>&1
+  echo examples done
+fi
+echo all done

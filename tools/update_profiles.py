@@ -1,0 +1,114 @@
+"""Copy the summaries tools/refresh_profiles.sh left under gpurun_out/final_<round> into profiles/<round>_* and refresh the k_pool
+entry of profiles/traffic.json.  Prints the numbers the docs quote.   python tools/update_profiles.py [r03]"""
+import csv
+import glob
+import json
+import os
+import shutil
+import subprocess
+import sys
+
+R = sys.argv[1] if len(sys.argv) > 1 else "r03"
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+O = os.path.join(ROOT, "gpurun_out", "final_" + R)
+P = os.path.join(ROOT, "profiles")
+
+
+def newest(pattern):
+    hits = sorted(glob.glob(os.path.join(O, pattern), recursive=True), key=os.path.getmtime)
+    return hits[-1] if hits else None
+
+
+def total(path, counter, needle):
+    t, n = 0.0, 0
+    for r in csv.DictReader(open(path)):
+        if r["Counter_Name"] == counter and needle in r["Kernel_Name"]:
+            t += float(r["Counter_Value"])
+            n += 1
+    return t, n
+
+
+def engine_rows(src, dst):  # keep the engine's kernels only (the files also hold torch / runtime kernels)
+    rows = list(csv.DictReader(open(src)))
+    keep = [r for r in rows if "azd::" in r["Kernel_Name"]]
+    with open(dst, "w", newline="") as f:
+        w = csv.DictWriter(f, fieldnames=list(rows[0].keys()))
+        w.writeheader()
+        w.writerows(keep)
+
+
+def txt(p):
+    return "".join(x for x in open(os.path.join(O, p)) if "amdgpu.ids" not in x)
+
+
+def bench_line(name):
+    path = os.path.join(O, f"bench_{name}.log")
+    if not os.path.exists(path):
+        return None
+    lines = [x for x in open(path).read().splitlines() if x.startswith('{"metric')]
+    return lines[-1] if lines else None
+
+
+ff, fw = newest("pmc_fetch/**/*counter_collection.csv"), newest("pmc_write/**/*counter_collection.csv")
+if ff and fw:
+    fetch, n1 = total(ff, "FETCH_SIZE", "k_pool")
+    write, n2 = total(fw, "WRITE_SIZE", "k_pool")
+    assert n1 == n2 and n1 > 0
+    calls = 800 * n1
+    raw = (fetch + write) * 1024 / calls
+    t = json.load(open(os.path.join(P, "traffic.json")))
+    t["k_pool"] = {
+        "kernel": "k_pool<3> (default step; %s: express lane, measured split; 4096 agents, default bench.py: three launches of 800 calls)" % R,
+        "FETCH_SIZE_KB_total": fetch, "WRITE_SIZE_KB_total": write, "calls": calls, "hbm_bytes_per_call": raw,
+        "hbm_bytes_per_call_if_every_request_were_128B": (2 * fetch + write) * 1024 / calls,
+        "calibration": "profiles/r02_gather_calib.txt (tools/probes/gather_calib.hip): FETCH_SIZE = 0.500 x the bytes of a coalesced 16-B-per-lane stream "
+                       "(the guide's x2 case), but 3.99 x the bytes of random 16-B record reads and 2.00 x those of random 32-B record reads, i.e. 64 B "
+                       "per missed record: the counter tallies one 64-B request per gather miss.  k_pool's reads from memory are record gathers "
+                       "(the evaluator's wide weight stream hits L2), so FETCH_SIZE is taken as it is; WRITE_SIZE is exact.",
+        "commands": [
+            "rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d gpurun_out/final_%s/pmc_fetch -- python3 bench.py --no-cpu-baseline" % R,
+            "rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d gpurun_out/final_%s/pmc_write -- python3 bench.py --no-cpu-baseline" % R,
+        ],
+    }
+    t["k_pool_hbm_bytes_per_call"] = raw
+    t["source"] = "%s_pool_pmc_fetch_size.csv + %s_pool_pmc_write_size.csv" % (R, R)
+    json.dump(t, open(os.path.join(P, "traffic.json"), "w"), indent=1)
+    engine_rows(ff, os.path.join(P, R + "_pool_pmc_fetch_size.csv"))
+    engine_rows(fw, os.path.join(P, R + "_pool_pmc_write_size.csv"))
+    print("k_pool traffic per call: %.1f MB (FETCH %.1f + WRITE %.1f)" % (raw / 1e6, fetch * 1024 / calls / 1e6, write * 1024 / calls / 1e6))
+for src, dst in (("prof/**/*kernel_stats.csv", "_pool_kernel_stats.csv"), ("prof20/**/*kernel_stats.csv", "_pool_driver20_kernel_stats.csv"),
+                 ("prof_E/**/*kernel_stats.csv", "_configE_kernel_stats.csv")):
+    f = newest(src)
+    if f:
+        shutil.copy(f, os.path.join(P, R + dst))
+        for row in csv.DictReader(open(f)):
+            if any(k in row["Name"] for k in ("k_pool", "k_gemm16", "k_rollout", "k_gemm_bf16")):
+                print("rocprofv3 %-28s %-60s launches %5s avg ms %.4f" % (dst, row["Name"][:60], row["Calls"], float(row["AverageNs"]) / 1e6))
+names = ("default", "driver20", "B_async", "A", "C", "D", "B8192", "E", "E612")
+with open(os.path.join(P, R + "_bench_lines.txt"), "w") as f:
+    for name in names:
+        line = bench_line(name)
+        if not line:
+            continue
+        f.write(f"### bench_{name}\n{line}\n")
+        d = json.loads(line)
+        print(f"{name:12s} {d['value'] / 1e6:6.2f} M  {d['ms_per_step'] * 1e3:7.1f} us/call  {d['step_form']:14s} frac {d['roofline']['frac']:.4f}  "
+              f"launch {d['roofline']['avg_launch_ms']:.2f} ms  split {d.get('pool_split')}")
+    for extra, title in (("curve.txt", "calls per launch (tools/launch_curve.py; the second block of each config: round 2's library, libazdopt_amd_r02.so)"),
+                         ("examples.txt", "examples/c21_tree (the reference's driver loop over the C ABI) at stride 1 and 800: 3 epochs x 800 episodes, 512 agents")):
+        if os.path.exists(os.path.join(O, extra)):
+            f.write("### %s\n%s" % (title, txt(extra)))
+for src, dst, head in (("gemm.txt", "_gemm.txt", "# tools/time_gemm16.py (the LDS-DMA bf16 GEMM in isolation, checked against torch) and tools/time_gemm.py (the evaluator's forward;\n# the last line: the round-2 kernel, AZD_GEMM_OLD=1)\n"),
+                       ("pool_split.txt", "_pool_split.txt", "# tools/split_util.py (busy shares of the two sides across fixed splits) and tools/split_feedback.py (the engine's feedback)\n")):
+    if os.path.exists(os.path.join(O, src)):
+        open(os.path.join(P, R + dst), "w").write(head + txt(src))
+sq = []
+for d_ in ("pmc_sq1", "pmc_sq2"):
+    if os.path.isdir(os.path.join(O, d_)):
+        sq.append(subprocess.run([sys.executable, os.path.join(ROOT, "tools", "pmc_sq.py"), os.path.join(O, d_), "k_pool"], capture_output=True, text=True).stdout)
+if sq:
+    open(os.path.join(P, R + "_pool_pmc_sq.txt"), "w").write("# SQ counters of k_pool<3>, two rocprofv3 --pmc passes over bench.py --steps 800 --warmup 800 (tools/refresh_profiles.sh); tools/pmc_sq.py\n" + "".join(sq))
+    print("".join(sq))
+m = [x for x in open(os.path.join(O, "prof.log")).read().splitlines() if x.startswith('{"metric')] if os.path.exists(os.path.join(O, "prof.log")) else []
+if m:
+    print("bench HIP-event avg in the profiled run:", json.loads(m[-1])["roofline"]["avg_launch_ms"])
