@@ -118,6 +118,7 @@ def lib():
     sig("azd_engine_destroy", C.c_int, vp)
     sig("azd_engine_par_new", C.c_int, vp, vp, vp)
     sig("azd_engine_par_roll_out_episodes", C.c_int, vp, vp, C.c_int, C.c_uint32, C.c_int, i32p)
+    sig("azd_engine_run_ahead", C.c_int, vp, vp, C.c_int, C.c_uint32, C.c_int, i32p)
     sig("azd_engine_par_update_model", C.c_int, vp, C.c_uint32, f32p)
     sig("azd_engine_par_update_model_sharded", C.c_int, vp, C.c_uint32, vp, f32p)
     sig("azd_engine_par_reset_trees", C.c_int, vp, vp, vp)

@@ -180,6 +180,26 @@ struct azd_engine {
     struct {
         int n_eval = 0; // what the next launch takes (0: the first guess)
     } pool_fb;
+    // Run-ahead window (azd_engine_run_ahead): one pool launch of n calls is under way, or over, and par_roll_out_episodes hands
+    // its calls out one by one from what the kernel publishes (PoolArgs::win_*) instead of launching anything.
+    struct Window {
+        bool open = false;    // calls run ahead of the host are still to be handed out
+        bool drained = false; // the launch behind them is over and its status is in
+        bool lumped = false;  // the launch aborted: the calls the take-over completed were reported together
+        int n = 0, consumed = 0;
+        azd::TolTable tol{};
+        uint32_t best_ord = 0;                // order key of the best cost as of `consumed` calls
+        unsigned long long best_key = ~0ull;  // its log entry (all ones: still the record from before the window)
+        unsigned long long side_key = ~0ull;  // what the side argmin record holds
+        unsigned long long base_improved = 0; // StatusRec::improved when the window opened
+        unsigned long long reported = 0;      // improvements handed out from this window
+        azd::FusedEval fe{};
+        azd::PoolArgs pool{};
+    } win;
+    unsigned long long *h_win_log = nullptr; // pinned, host-coherent [log_calls]
+    uint32_t *h_win_flag = nullptr;          // pinned, host-coherent [log_calls]
+    azd::ArgminRec *d_argmin_side = nullptr; // the argmin record as of a call inside the window (k_argmin_one)
+    azd::RamseyArgminRec *d_argmin_r_side = nullptr;
     float *d_pool = nullptr;      // pooled training triple of all ranks (azd_engine_par_update_model_sharded)
     size_t pool_rows = 0;
     int step_form = 0;            // AZD_STEP_* chosen by the last par_roll_out_episodes
@@ -229,9 +249,28 @@ struct azd_engine {
     }
 };
 
+static int window_close(azd_engine *e);
+// Entry of every call that changes or reads what a running launch works on: the device is selected and a run-ahead window, if
+// one is open, is closed first (its launch is waited for; calls not yet handed out have run and stay run).
+#define AZD_ENTER(e)                                \
+    do {                                            \
+        AZD_HIP(hipSetDevice((e)->cfg.device));     \
+        if ((e)->win.open) {                        \
+            const int st_w_ = window_close(e);      \
+            if (st_w_) return st_w_;                \
+        }                                           \
+    } while (0)
+
 namespace {
 
 using namespace azd;
+
+uint32_t host_ordf(float f) { // tree_core.inc ordf
+    f = f + 0.0f;
+    uint32_t u;
+    memcpy(&u, &f, 4);
+    return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
 
 bool pool_feedback_on() {
     const char *env = getenv("AZD_POOL_FEEDBACK");
@@ -760,6 +799,19 @@ int azd_engine_create(azd_engine **out, const azd_engine_config *cfg, azd_evalua
         }
         TRY(e->alloc(&e->d_log_key, (size_t)e->log_calls * n_wg));
         TRY(e->alloc(&e->d_log_node, (size_t)e->log_calls * n_wg));
+        TRY(e->alloc(&e->pool.win_count, (size_t)e->log_calls));
+        TRY(e->alloc(&e->d_argmin_side, 1));
+        if (ramsey) TRY(e->alloc(&e->d_argmin_r_side, 1));
+        // what the kernel hands the host in the middle of a launch: fine-grained (host-coherent) pinned memory
+        hipError_t he3 = hipHostMalloc((void **)&e->h_win_log, (size_t)e->log_calls * sizeof(unsigned long long), hipHostMallocCoherent);
+        if (he3 == hipSuccess) he3 = hipHostMalloc((void **)&e->h_win_flag, (size_t)e->log_calls * sizeof(uint32_t), hipHostMallocCoherent);
+        if (he3 != hipSuccess) {
+            st = azd::hip_fail(he3, "hipHostMalloc");
+            azd_engine_destroy(e);
+            return st;
+        }
+        e->pool.win_log = e->h_win_log;
+        e->pool.win_flag = e->h_win_flag;
     }
     TRY(e->alloc(&e->d_stage_parents, B * (size_t)(dense ? 8 * a.n : ramsey ? a.E : a.n)));
     TRY(e->alloc(&e->d_stage_perm, B * (size_t)(dense ? 17 * a.KW : a.KW)));
@@ -798,6 +850,8 @@ int azd_engine_destroy(azd_engine *e) {
     if (e->h_status) (void)hipHostFree(e->h_status);
     if (e->h_argmin) (void)hipHostFree(e->h_argmin);
     if (e->h_pargs) (void)hipHostFree(e->h_pargs);
+    if (e->h_win_log) (void)hipHostFree(e->h_win_log);
+    if (e->h_win_flag) (void)hipHostFree(e->h_win_flag);
     if (e->d_pool) (void)hipFree(e->d_pool);
     if (e->call_graph) (void)hipGraphExecDestroy(e->call_graph);
     for (int i = 0; i < azd_engine::MAX_SUBS; ++i) {
@@ -819,7 +873,7 @@ int azd_engine_destroy(azd_engine *e) {
 // optimizer/mod.rs:61-70
 int azd_engine_par_new_begin(azd_engine *e, const uint8_t *parents, const uint64_t *permitted) {
     if (!e || !parents || !permitted) return AZD_ERR_INVALID_ARGUMENT;
-    AZD_HIP(hipSetDevice(e->cfg.device));
+    AZD_ENTER(e);
     int st = upload_roots(e, parents, permitted);
     if (st) return st;
     const azd::Arenas &a = e->a;
@@ -840,7 +894,7 @@ static int new_finish(azd_engine *e) {
 // optimizer/mod.rs:74-101
 int azd_engine_par_new_end(azd_engine *e, const float *h_theta) {
     if (!e || !h_theta) return AZD_ERR_INVALID_ARGUMENT;
-    AZD_HIP(hipSetDevice(e->cfg.device));
+    AZD_ENTER(e);
     AZD_HIP(hipMemcpyAsync(e->a.h_theta, h_theta, (size_t)e->a.B * e->a.A * 4, hipMemcpyHostToDevice, e->stream));
     return new_finish(e);
 }
@@ -857,7 +911,7 @@ int azd_engine_par_new(azd_engine *e, const uint8_t *parents, const uint64_t *pe
 // optimizer/mod.rs:159-174
 int azd_engine_roll_out_begin(azd_engine *e, const uint32_t *tol, int n_tol, uint32_t dflt) {
     if (!e || !e->initialised) return AZD_ERR_INVALID_ARGUMENT;
-    AZD_HIP(hipSetDevice(e->cfg.device));
+    AZD_ENTER(e);
     azd::TolTable t;
     int st = fill_tol(t, tol, n_tol, dflt);
     if (st) return st;
@@ -869,7 +923,7 @@ int azd_engine_roll_out_begin(azd_engine *e, const uint32_t *tol, int n_tol, uin
 // optimizer/mod.rs:177-190
 int azd_engine_roll_out_end(azd_engine *e, const float *h_theta, int *improved) {
     if (!e || !h_theta || !e->initialised) return AZD_ERR_INVALID_ARGUMENT;
-    AZD_HIP(hipSetDevice(e->cfg.device));
+    AZD_ENTER(e);
     AZD_HIP(hipMemcpyAsync(e->a.h_theta, h_theta, (size_t)e->a.B * e->a.A * 4, hipMemcpyHostToDevice, e->stream));
     azd::launch_add_actions(e->a, 0, e->stream);
     azd::launch_argmin(e->a, 0, e->stream);
@@ -878,14 +932,71 @@ int azd_engine_roll_out_end(azd_engine *e, const float *h_theta, int *improved) 
     e->seen_improved = e->h_status->improved;
     return st;
 }
-int azd_engine_par_roll_out_episodes(azd_engine *e, const uint32_t *tol, int n_tol, uint32_t dflt, int n_calls,
-                                     int *improved) {
-    if (!e || n_calls < 0 || !e->initialised) return AZD_ERR_INVALID_ARGUMENT;
-    if (!e->ev) return AZD_ERR_NO_EVALUATOR;
-    AZD_HIP(hipSetDevice(e->cfg.device));
-    azd::TolTable t;
-    int st = fill_tol(t, tol, n_tol, dflt);
+static int pool_clear(azd_engine *e, const azd::PoolArgs &pool) { // empty queues, nobody claimed, no call done
+    AZD_HIP(hipMemsetAsync(pool.ctl, 0, sizeof(azd::PoolCtl), e->stream));
+    AZD_HIP(hipMemsetAsync(pool.ready_slots, 0, e->pool_slot_words * sizeof(uint32_t), e->stream));
+    AZD_HIP(hipMemsetAsync(pool.join, 0, (size_t)e->a.B * sizeof(uint32_t), e->stream));
+    e->pool_clean = true;
+    return AZD_OK;
+}
+
+// What follows a pool launch of k calls on the host: its status block (the two sides' busy shares, for the split feedback) and
+// -- when a wait ran into its bound -- the take-over.
+// A wait that ran into its bound ends a pool launch instead of hanging it (PoolCtl::abort; k_argmin_log1 has put the flag into
+// the status block and left the log alone).  The trees are consistent -- a wave never leaves an agent inside a call -- so the
+// asynchronous step, whose workgroups need no company, takes the launch over where every agent stands, and this engine stays
+// with it (*took_over; the asynchronous step's LDS plan in *as_out / *ab_out).
+static int pool_finish_launch(azd_engine *e, const azd::FusedEval &fe, const azd::PoolArgs &pool, int k, bool *took_over,
+                              uint32_t *as_out, size_t *ab_out) {
+    *took_over = false;
+    int st = fetch_status(e);
     if (st) return st;
+    if (e->h_status->pool_ticks > 0 && !e->h_status->pool_abort) {
+        const double T = (double)e->h_status->pool_ticks;
+        e->pool_util_eval = e->pool_eval_wgs > 0 ? (double)e->h_status->pool_eval_busy / (T * e->pool_eval_wgs) : 0.0;
+        e->pool_util_search = e->pool_search_waves > 0 ? (double)e->h_status->pool_search_busy / (T * e->pool_search_waves) : 0.0;
+    }
+    if (!e->h_status->pool_abort) return AZD_OK;
+    e->pool_clean = false;
+    e->log_clean = false; // (it holds the aborted launch's candidates, which the take-over's replay needs: not cleared here)
+    e->pool_failed = true;
+    e->pool_step = false;
+    uint32_t as = 0;
+    size_t ab = 0;
+    const char *why_t = "";
+    if (!azd::async_plan(e->a, fe, &as, &ab, &why_t)) {
+        e->time_collect();
+        azd::g_last_error = std::string("pool step: a queue wait ran into its bound, and the asynchronous step cannot take over: ") + why_t;
+        return AZD_ERR_UNREACHABLE;
+    }
+    azd::launch_pool_resume_scan(e->a, pool, k, e->d_resume, e->stream);
+    st = pool_clear(e, pool);
+    if (st) return st;
+    azd::StepLaunch sl;
+    sl.n_calls = k;
+    sl.log_key = e->d_log_key;
+    sl.resume = e->d_resume;
+    sl.ctl = nullptr;
+    sl.hashed = fe.kind == 4;
+    sl.window = 0;
+    e->time_begin(0);
+    azd::launch_async(e->a, e->d_pargs, sl, fe.params, fe.wpk, as, ab, e->stream);
+    e->time_end();
+    e->log_clean = true; // k_argmin_log1 has replayed and cleared it
+    e->step_form = AZD_STEP_ASYNC;
+    e->step_reason = "pool step aborted (a queue wait ran into its bound: no evaluator or searcher workgroup made progress); "
+                     "the asynchronous step took the launch over and serves this engine from here on";
+    *took_over = true;
+    *as_out = as;
+    *ab_out = ab;
+    return AZD_OK;
+}
+
+// optimizer/mod.rs:159-190, n_calls times.  ahead: azd_engine_run_ahead -- the launch is left running and its calls are handed
+// out by window_serve; *accepted = 0 when this engine's step form cannot do that (nothing is launched then).
+static int roll_out_impl(azd_engine *e, const azd::TolTable &t, int n_calls, int *improved, bool ahead, int *accepted) {
+    int st = AZD_OK;
+    if (accepted) *accepted = 0;
     azd::FusedEval fe;
     uint32_t dyn_stride = 0;
     size_t dyn_bytes = 0;
@@ -1025,6 +1136,11 @@ int azd_engine_par_roll_out_episodes(azd_engine *e, const uint32_t *tol, int n_t
         if (!use_async && !use_barrier && *why_b) e->step_reason += std::string("; ") + why_b;
     }
     e->step_form = use_pool ? AZD_STEP_POOL : use_async ? AZD_STEP_ASYNC : use_barrier ? AZD_STEP_BARRIER : AZD_STEP_PER_CALL;
+    if (ahead) { // only the pool step publishes its calls while it runs, one launch's worth of them
+        const bool ok = use_pool && fe.kind >= 3 && n_calls >= 1 && n_calls <= e->log_calls && !e->timing;
+        if (!ok) return AZD_OK; // a hint: the calls run when they are asked for
+        *accepted = 1;
+    }
     if (use_pool || use_async || use_barrier) {
         // CU-resident forms: the whole call chain, n_calls times, in one launch per <= log_calls calls.  What a launch costs
         // the host: the argument block is re-sent only when it changed (per-launch values are kernel arguments), the log and
@@ -1046,13 +1162,6 @@ int azd_engine_par_roll_out_episodes(azd_engine *e, const uint32_t *tol, int n_t
             e->pargs_valid = true;
             return AZD_OK;
         };
-        auto clear_pool = [&]() -> int { // empty queues, nobody claimed, no call done
-            AZD_HIP(hipMemsetAsync(pool.ctl, 0, sizeof(azd::PoolCtl), e->stream));
-            AZD_HIP(hipMemsetAsync(pool.ready_slots, 0, e->pool_slot_words * sizeof(uint32_t), e->stream));
-            AZD_HIP(hipMemsetAsync(pool.join, 0, (size_t)e->a.B * sizeof(uint32_t), e->stream));
-            e->pool_clean = true;
-            return AZD_OK;
-        };
         const bool fb_on = use_pool && fe.kind == 3 && pool_feedback_on() && n_calls >= 100 && !getenv("AZD_POOL_EVAL_WGS");
         int left = n_calls;
         while (left > 0) {
@@ -1061,12 +1170,25 @@ int azd_engine_par_roll_out_episodes(azd_engine *e, const uint32_t *tol, int n_t
             st = send_args(pool);
             if (st) return st;
             if (use_pool && !e->pool_clean) {
-                st = clear_pool();
+                st = pool_clear(e, pool);
                 if (st) return st;
             }
             if (!use_barrier && !e->log_clean) {
                 AZD_HIP(hipMemsetAsync(e->d_log_key, 0xFF, (size_t)e->log_calls * sizeof(unsigned long long), e->stream));
                 e->log_clean = true;
+            }
+            if (ahead) {
+                // the window's hand-over words (no launch that writes them is in flight: a window is drained before the next opens),
+                // and the argmin record the window starts from: its cost for the host's per-call compare, a copy for argmin_data
+                AZD_HIP(hipMemsetAsync(pool.win_count, 0, (size_t)e->log_calls * sizeof(uint32_t), e->stream));
+                AZD_HIP(hipMemcpyAsync(e->d_argmin_side, e->a.argmin, sizeof(azd::ArgminRec), hipMemcpyDeviceToDevice, e->stream));
+                if (e->d_argmin_r_side)
+                    AZD_HIP(hipMemcpyAsync(e->d_argmin_r_side, e->a.argmin_r, sizeof(azd::RamseyArgminRec), hipMemcpyDeviceToDevice, e->stream));
+                AZD_HIP(hipMemcpyAsync(e->h_argmin, e->a.argmin, sizeof(azd::ArgminRec), hipMemcpyDeviceToHost, e->stream));
+                st = fetch_status(e); // (synchronises)
+                if (st) return st;
+                memset(e->h_win_flag, 0, (size_t)e->log_calls * sizeof(uint32_t));
+                __atomic_thread_fence(__ATOMIC_SEQ_CST);
             }
             azd::StepLaunch sl;
             sl.n_calls = k;
@@ -1074,6 +1196,7 @@ int azd_engine_par_roll_out_episodes(azd_engine *e, const uint32_t *tol, int n_t
             sl.resume = nullptr;
             sl.ctl = use_pool ? pool.ctl : nullptr;
             sl.hashed = fe.kind == 4;
+            sl.window = ahead ? 1 : 0;
             e->time_begin(0);
             if (use_pool) azd::launch_pool(e->a, e->d_pargs, sl, fe.params, fe.wpk, pool_blocks, dyn_stride, dyn_bytes, e->stream);
             else if (use_async) azd::launch_async(e->a, e->d_pargs, sl, fe.params, fe.wpk, dyn_stride, dyn_bytes, e->stream);
@@ -1083,50 +1206,29 @@ int azd_engine_par_roll_out_episodes(azd_engine *e, const uint32_t *tol, int n_t
             }
             e->time_end();
             left -= k;
+            if (ahead) { // the launch is on its way; window_serve / window_drain do the rest
+                AZD_HIP(hipGetLastError());
+                e->ev->calls += (uint64_t)k;
+                azd_engine::Window &w = e->win;
+                w = azd_engine::Window();
+                w.open = true;
+                w.n = k;
+                w.tol = t;
+                w.best_ord = host_ordf(e->h_argmin->eval);
+                w.base_improved = e->h_status->improved;
+                w.fe = fe;
+                w.pool = pool;
+                if (improved) *improved = 0;
+                return AZD_OK;
+            }
             if (use_pool) {
-                // A wait that ran into its bound ends a pool launch instead of hanging it (PoolCtl::abort; k_argmin_log1 has put
-                // the flag into the status block and left the log alone).  The trees are consistent -- a wave never leaves an
-                // agent inside a call -- so the asynchronous step, whose workgroups need no company, takes the launch over
-                // where every agent stands, and this engine stays with it.
-                st = fetch_status(e);
+                bool took_over = false;
+                st = pool_finish_launch(e, fe, pool, k, &took_over, &dyn_stride, &dyn_bytes);
                 if (st) return st;
-                status_fresh = left == 0; // the last launch's status is in, and nothing ran behind it
-                if (e->h_status->pool_ticks > 0 && !e->h_status->pool_abort) {
-                    const double T = (double)e->h_status->pool_ticks;
-                    e->pool_util_eval = e->pool_eval_wgs > 0 ? (double)e->h_status->pool_eval_busy / (T * e->pool_eval_wgs) : 0.0;
-                    e->pool_util_search = e->pool_search_waves > 0 ? (double)e->h_status->pool_search_busy / (T * e->pool_search_waves) : 0.0;
-                }
-                if (e->h_status->pool_abort) {
-                    e->pool_clean = false;
-                    e->log_clean = false; // (it holds the aborted launch's candidates, which the take-over's replay needs: not cleared here)
-                    e->pool_failed = true;
-                    e->pool_step = false;
-                    uint32_t as = 0;
-                    size_t ab = 0;
-                    const char *why_t = "";
-                    if (!azd::async_plan(e->a, fe, &as, &ab, &why_t)) {
-                        e->time_collect();
-                        azd::g_last_error = std::string("pool step: a queue wait ran into its bound, and the asynchronous step cannot take over: ") + why_t;
-                        return AZD_ERR_UNREACHABLE;
-                    }
-                    azd::launch_pool_resume_scan(e->a, pool, k, e->d_resume, e->stream);
-                    st = clear_pool();
-                    if (st) return st;
-                    e->pool_clean = true;
-                    sl.resume = e->d_resume;
-                    sl.ctl = nullptr;
-                    e->time_begin(0);
-                    azd::launch_async(e->a, e->d_pargs, sl, fe.params, fe.wpk, as, ab, e->stream);
-                    e->time_end();
-                    e->log_clean = true; // k_argmin_log1 has replayed and cleared it
-                    status_fresh = false;
-                    e->step_form = AZD_STEP_ASYNC;
-                    e->step_reason = "pool step aborted (a queue wait ran into its bound: no evaluator or searcher workgroup made progress); "
-                                     "the asynchronous step took the launch over and serves this engine from here on";
+                status_fresh = left == 0 && !took_over; // the last launch's status is in, and nothing ran behind it
+                if (took_over) {
                     use_pool = false;
                     use_async = true;
-                    dyn_stride = as;
-                    dyn_bytes = ab;
                 }
             }
             e->ev->calls += (uint64_t)k;
@@ -1275,11 +1377,157 @@ int azd_engine_par_roll_out_episodes(azd_engine *e, const uint32_t *tol, int n_t
     return st;
 }
 
+// ---------------------------------------------------------------- run-ahead window
+// The launch behind the window is over (or is waited for here): status in, busy shares noted, an aborted launch taken over.
+static int window_drain(azd_engine *e) {
+    azd_engine::Window &w = e->win;
+    if (w.drained) return AZD_OK;
+    bool took_over = false;
+    uint32_t as = 0;
+    size_t ab = 0;
+    int st = pool_finish_launch(e, w.fe, w.pool, w.n, &took_over, &as, &ab);
+    if (st) return st;
+    if (took_over) {
+        st = fetch_status(e);
+        if (st) return st;
+    }
+    w.drained = true;
+    return check_status(e);
+}
+// The window ends: every call it ran is accounted for, whether handed out or not.
+static int window_close(azd_engine *e) {
+    azd_engine::Window &w = e->win;
+    if (!w.open) return AZD_OK;
+    const int st = window_drain(e);
+    w.open = false;
+    if (st) return st;
+    // every improvement the host was told of, call by call, is one the device's replay of the same log counted
+    const unsigned long long total = e->h_status->improved - w.base_improved;
+    if (w.consumed == w.n && !w.lumped && w.reported != total) {
+        char buf[160];
+        snprintf(buf, sizeof(buf), "run-ahead window: %llu improvements handed out call by call, %llu in the device's replay", w.reported, total);
+        azd::g_last_error = buf;
+        e->seen_improved = e->h_status->improved;
+        return AZD_ERR_UNREACHABLE;
+    }
+    e->seen_improved = e->h_status->improved;
+    return AZD_OK;
+}
+// k calls of the window, in order: each is waited for (the kernel publishes a call once its last agent is through it) and
+// compared with the best cost so far exactly as k_argmin_log1 will compare it (strict, optimizer/mod.rs:211).
+static int window_serve(azd_engine *e, int k, int *improved) {
+    azd_engine::Window &w = e->win;
+    int imp = 0;
+    for (int i = w.consumed; i < w.consumed + k; ++i) {
+        uint32_t spins = 0;
+        while (!w.drained && __atomic_load_n(&e->h_win_flag[i], __ATOMIC_ACQUIRE) == 0u) {
+            if ((++spins & 255u) == 0u) {
+                const hipError_t q = hipStreamQuery(e->stream);
+                if (q == hipSuccess) { // the launch is over: whatever it has not published it will not (an abort)
+                    const int st = window_drain(e);
+                    if (st) {
+                        w.open = false;
+                        e->seen_improved = e->h_status->improved;
+                        return st;
+                    }
+                } else if (q != hipErrorNotReady) return azd::hip_fail(q, "hipStreamQuery");
+            }
+#if defined(__x86_64__)
+            __builtin_ia32_pause();
+#endif
+        }
+        if (__atomic_load_n(&e->h_win_flag[i], __ATOMIC_ACQUIRE) != 0u) {
+            const unsigned long long key = e->h_win_log[i];
+            if (key != ~0ull && (uint32_t)(key >> 32) < w.best_ord) {
+                w.best_ord = (uint32_t)(key >> 32);
+                w.best_key = key;
+                imp += 1;
+            }
+        } else if (!w.lumped) {
+            // an aborted launch: the take-over completed the calls from here on and does not publish them one by one -- what they
+            // improved is reported with this call, and the argmin record is the one the launch ended with
+            const unsigned long long total = e->h_status->improved - w.base_improved;
+            imp += (int)(total - w.reported - (unsigned long long)imp);
+            w.lumped = true;
+        }
+    }
+    w.consumed += k;
+    w.reported += (unsigned long long)imp;
+    if (improved) *improved = imp;
+    if (w.consumed == w.n) return window_close(e);
+    return AZD_OK;
+}
+// argmin_data inside a window: the record as of the calls handed out.  The winner's replay reads its tree, so the launch is
+// waited for; the calls not yet handed out stay in the window.
+static int window_argmin_side(azd_engine *e, bool *side) {
+    azd_engine::Window &w = e->win;
+    *side = false;
+    if (!w.open) return AZD_OK;
+    const int st = window_drain(e);
+    if (st) {
+        w.open = false;
+        e->seen_improved = e->h_status->improved;
+        return st;
+    }
+    if (w.lumped) return AZD_OK; // (the device's record is all there is)
+    if (w.best_key != w.side_key) {
+        azd::Arenas a2 = e->a;
+        a2.argmin = e->d_argmin_side;
+        a2.argmin_r = e->d_argmin_r_side;
+        azd::launch_argmin_one(a2, (int)((w.best_key >> 16) & 0xFFFFull), (uint32_t)(w.best_key & 0xFFFFull), e->stream);
+        AZD_HIP(hipGetLastError());
+        w.side_key = w.best_key;
+    }
+    *side = true;
+    return AZD_OK;
+}
+
+int azd_engine_par_roll_out_episodes(azd_engine *e, const uint32_t *tol, int n_tol, uint32_t dflt, int n_calls,
+                                     int *improved) {
+    if (!e || n_calls < 0 || !e->initialised) return AZD_ERR_INVALID_ARGUMENT;
+    if (!e->ev) return AZD_ERR_NO_EVALUATOR;
+    AZD_HIP(hipSetDevice(e->cfg.device));
+    azd::TolTable t;
+    int st = fill_tol(t, tol, n_tol, dflt);
+    if (st) return st;
+    if (e->win.open) {
+        // calls that were run ahead: handed out without a launch.  Other calls (another tolerance table, more calls than the
+        // window has left) close the window and run as usual.
+        if (memcmp(&e->win.tol, &t, sizeof(t)) == 0 && n_calls <= e->win.n - e->win.consumed) {
+            if (n_calls == 0) {
+                if (improved) *improved = 0;
+                return AZD_OK;
+            }
+            return window_serve(e, n_calls, improved);
+        }
+        st = window_close(e);
+        if (st) return st;
+    }
+    return roll_out_impl(e, t, n_calls, improved, false, nullptr);
+}
+
+// Run-ahead window: the next n_calls calls of par_roll_out_episodes(tol, ...) are started now, in one launch, and the calls
+// that ask for them -- one by one, or in any chunks -- are answered from what the kernel publishes as it goes.
+int azd_engine_run_ahead(azd_engine *e, const uint32_t *tol, int n_tol, uint32_t dflt, int n_calls, int *accepted) {
+    if (accepted) *accepted = 0;
+    if (!e || n_calls < 0 || !e->initialised) return AZD_ERR_INVALID_ARGUMENT;
+    if (!e->ev) return AZD_ERR_NO_EVALUATOR;
+    AZD_ENTER(e);
+    azd::TolTable t;
+    int st = fill_tol(t, tol, n_tol, dflt);
+    if (st) return st;
+    if (n_calls == 0) return AZD_OK;
+    int ok = 0;
+    st = roll_out_impl(e, t, n_calls, nullptr, true, &ok);
+    if (accepted) *accepted = ok;
+    return st;
+}
+
 // optimizer/mod.rs:262-278
 int azd_engine_observe_dev(azd_engine *e, uint32_t n_obs_tol, const float **d_state_vecs, const float **d_obs,
                            const float **d_w) {
     if (!e || !e->initialised) return AZD_ERR_INVALID_ARGUMENT;
-    AZD_HIP(hipSetDevice(e->cfg.device));
+    AZD_ENTER(e);
     azd::launch_observe(e->a, n_obs_tol, e->stream);
     AZD_HIP(hipStreamSynchronize(e->stream));
     AZD_HIP(hipGetLastError());
@@ -1300,7 +1548,7 @@ int azd_engine_observe(azd_engine *e, uint32_t n_obs_tol, float *state_vecs, flo
 int azd_engine_par_update_model(azd_engine *e, uint32_t n_obs_tol, float *loss) {
     if (!e || !e->initialised) return AZD_ERR_INVALID_ARGUMENT;
     if (!e->ev) return AZD_ERR_NO_EVALUATOR;
-    AZD_HIP(hipSetDevice(e->cfg.device));
+    AZD_ENTER(e);
     azd::launch_observe(e->a, n_obs_tol, e->stream);
     AZD_HIP(hipGetLastError());
     float l = 0.f;
@@ -1344,7 +1592,7 @@ constexpr int NCCL_FLOAT32 = 7; // ncclFloat32 (rccl.h)
 int azd_engine_par_update_model_sharded(azd_engine *e, uint32_t n_obs_tol, void *nccl_comm, float *loss) {
     if (!e || !e->initialised || !nccl_comm) return AZD_ERR_INVALID_ARGUMENT;
     if (!e->ev) return AZD_ERR_NO_EVALUATOR;
-    AZD_HIP(hipSetDevice(e->cfg.device));
+    AZD_ENTER(e);
     RcclApi &api = *rccl();
     if (!api.allGather || !api.commCount) {
         azd::g_last_error = "librccl.so could not be loaded (ncclAllGather / ncclCommCount)";
@@ -1397,7 +1645,7 @@ int azd_engine_par_update_model_sharded(azd_engine *e, uint32_t n_obs_tol, void 
 // optimizer/mod.rs:317-346
 int azd_engine_reset_begin(azd_engine *e, const uint8_t *parents, const uint64_t *permitted) {
     if (!e || !parents || !permitted || !e->initialised) return AZD_ERR_INVALID_ARGUMENT;
-    AZD_HIP(hipSetDevice(e->cfg.device));
+    AZD_ENTER(e);
     int st = upload_roots(e, parents, permitted);
     if (st) return st;
     const azd::Arenas &a = e->a;
@@ -1413,7 +1661,7 @@ static int reset_finish(azd_engine *e) {
 }
 int azd_engine_reset_end(azd_engine *e, const float *h_theta) {
     if (!e || !h_theta) return AZD_ERR_INVALID_ARGUMENT;
-    AZD_HIP(hipSetDevice(e->cfg.device));
+    AZD_ENTER(e);
     AZD_HIP(hipMemcpyAsync(e->a.h_theta, h_theta, (size_t)e->a.B * e->a.A * 4, hipMemcpyHostToDevice, e->stream));
     return reset_finish(e);
 }
@@ -1457,7 +1705,7 @@ int azd_engine_par_reset_trees_c21(azd_engine *e, uint64_t seed, uint64_t epoch,
     int st = c21_policy_args_ok(e, kmin, kmax);
     if (st) return st;
     if (!e->ev) return AZD_ERR_NO_EVALUATOR;
-    AZD_HIP(hipSetDevice(e->cfg.device));
+    AZD_ENTER(e);
     const azd::Arenas &a = e->a;
     if (a.space == azd::SPACE_DENSE)
         azd::dense_launch_modify_roots(a, seed, epoch, e->cfg.first_agent, kmin, kmax, e->d_stage_parents, e->d_stage_perm, e->d_stage_slots, e->stream);
@@ -1475,7 +1723,7 @@ int azd_c21_modify_roots_dev(azd_engine *e, uint64_t seed, uint64_t epoch, int k
     int st = c21_policy_args_ok(e, kmin, kmax);
     if (st) return st;
     if (!parents_out || !permitted_out) return AZD_ERR_INVALID_ARGUMENT;
-    AZD_HIP(hipSetDevice(e->cfg.device));
+    AZD_ENTER(e);
     const azd::Arenas &a = e->a;
     if (a.space == azd::SPACE_DENSE) { // roots_out: neighbourhoods (8 n bytes per root); permitted_out: slot masks in kw_host words per root
         azd::dense_launch_modify_roots(a, seed, epoch, e->cfg.first_agent, kmin, kmax, e->d_stage_parents, e->d_stage_perm, e->d_stage_slots, e->stream);
@@ -1510,15 +1758,20 @@ int azd_engine_ramsey_argmin_data(azd_engine *e, azd_ramsey_argmin *out) {
     if (!e || !out || !e->initialised) return AZD_ERR_INVALID_ARGUMENT;
     if (e->a.space != azd::SPACE_RAMSEY) return AZD_ERR_UNSUPPORTED;
     AZD_HIP(hipSetDevice(e->cfg.device));
+    bool side = false; // inside a run-ahead window: the record as of the calls handed out so far
+    {
+        const int st_w = window_argmin_side(e, &side);
+        if (st_w) return st_w;
+    }
     static_assert(sizeof(azd_ramsey_argmin) == sizeof(azd::RamseyArgminRec), "ABI struct mismatch");
     AZD_HIP(hipStreamSynchronize(e->stream));
-    AZD_HIP(hipMemcpy(out, e->a.argmin_r, sizeof(azd_ramsey_argmin), hipMemcpyDeviceToHost));
+    AZD_HIP(hipMemcpy(out, side ? e->d_argmin_r_side : e->a.argmin_r, sizeof(azd_ramsey_argmin), hipMemcpyDeviceToHost));
     return AZD_OK;
 }
 int azd_engine_dense_argmin_data(azd_engine *e, azd_dense_argmin *out) {
     if (!e || !out || !e->initialised) return AZD_ERR_INVALID_ARGUMENT;
     if (e->a.space != azd::SPACE_DENSE) return AZD_ERR_UNSUPPORTED;
-    AZD_HIP(hipSetDevice(e->cfg.device));
+    AZD_ENTER(e);
     static_assert(sizeof(azd_dense_argmin) == sizeof(azd::DenseArgminRec), "ABI struct mismatch");
     AZD_HIP(hipStreamSynchronize(e->stream));
     AZD_HIP(hipMemcpy(out, e->a.argmin_d, sizeof(azd_dense_argmin), hipMemcpyDeviceToHost));
@@ -1527,7 +1780,7 @@ int azd_engine_dense_argmin_data(azd_engine *e, azd_dense_argmin *out) {
 int azd_engine_ramsey_agent_counts(azd_engine *e, int agent, int32_t *counts, int32_t *totals) {
     if (!e || agent < 0 || agent >= e->a.B) return AZD_ERR_INVALID_ARGUMENT;
     if (e->a.space != azd::SPACE_RAMSEY) return AZD_ERR_UNSUPPORTED;
-    AZD_HIP(hipSetDevice(e->cfg.device));
+    AZD_ENTER(e);
     AZD_HIP(hipStreamSynchronize(e->stream));
     const azd::Arenas &a = e->a;
     if (counts) AZD_HIP(hipMemcpy(counts, a.cur_counts + (size_t)agent * a.C * a.E, (size_t)a.C * a.E * 4, hipMemcpyDeviceToHost));
@@ -1539,8 +1792,13 @@ int azd_engine_argmin_data(azd_engine *e, azd_argmin *out) {
     if (!e || !out || !e->initialised) return AZD_ERR_INVALID_ARGUMENT;
     if (e->a.space != azd::SPACE_C21) return AZD_ERR_UNSUPPORTED;
     AZD_HIP(hipSetDevice(e->cfg.device));
+    bool side = false; // inside a run-ahead window: the record as of the calls handed out so far
+    {
+        const int st_w = window_argmin_side(e, &side);
+        if (st_w) return st_w;
+    }
     static_assert(sizeof(azd_argmin) == sizeof(azd::ArgminRec), "ABI struct mismatch");
-    AZD_HIP(hipMemcpyAsync(e->h_argmin, e->a.argmin, sizeof(azd::ArgminRec), hipMemcpyDeviceToHost, e->stream));
+    AZD_HIP(hipMemcpyAsync(e->h_argmin, side ? e->d_argmin_side : e->a.argmin, sizeof(azd::ArgminRec), hipMemcpyDeviceToHost, e->stream));
     AZD_HIP(hipStreamSynchronize(e->stream));
     memcpy(out, e->h_argmin, sizeof(azd_argmin));
     return AZD_OK;
@@ -1548,14 +1806,14 @@ int azd_engine_argmin_data(azd_engine *e, azd_argmin *out) {
 
 int azd_engine_read_state_vecs(azd_engine *e, float *out) {
     if (!e || !out) return AZD_ERR_INVALID_ARGUMENT;
-    AZD_HIP(hipSetDevice(e->cfg.device));
+    AZD_ENTER(e);
     AZD_HIP(hipStreamSynchronize(e->stream));
     AZD_HIP(hipMemcpy(out, e->a.state_vecs, (size_t)e->a.B * e->a.S * 4, hipMemcpyDeviceToHost));
     return AZD_OK;
 }
 int azd_engine_read_predictions(azd_engine *e, float *out) {
     if (!e || !out) return AZD_ERR_INVALID_ARGUMENT;
-    AZD_HIP(hipSetDevice(e->cfg.device));
+    AZD_ENTER(e);
     AZD_HIP(hipStreamSynchronize(e->stream));
     AZD_HIP(hipMemcpy(out, e->a.h_theta, (size_t)e->a.B * e->a.A * 4, hipMemcpyDeviceToHost));
     return AZD_OK;
@@ -1563,7 +1821,7 @@ int azd_engine_read_predictions(azd_engine *e, float *out) {
 
 int azd_engine_tree_sizes(azd_engine *e, int agent, int *n_nodes, int *n_arcs, int *n_preds) {
     if (!e || agent < 0 || agent >= e->a.B) return AZD_ERR_INVALID_ARGUMENT;
-    AZD_HIP(hipSetDevice(e->cfg.device));
+    AZD_ENTER(e);
     AZD_HIP(hipStreamSynchronize(e->stream));
     uint32_t v[3];
     AZD_HIP(hipMemcpy(&v[0], e->a.n_nodes + agent, 4, hipMemcpyDeviceToHost));
@@ -1624,7 +1882,7 @@ int azd_engine_export_tree(azd_engine *e, int agent, float *c, float *c_star, ui
 int azd_engine_agent_state(azd_engine *e, int agent, uint8_t *parents, uint64_t *permitted, uint64_t *path,
                            uint32_t *state_pos, double *lambda_1, int *matching_size) {
     if (!e || agent < 0 || agent >= e->a.B) return AZD_ERR_INVALID_ARGUMENT;
-    AZD_HIP(hipSetDevice(e->cfg.device));
+    AZD_ENTER(e);
     AZD_HIP(hipStreamSynchronize(e->stream));
     const azd::Arenas &a = e->a;
     if (a.space == azd::SPACE_DENSE) { // `parents` receives the neighbourhoods (8 n bytes); masks are kw_host words
@@ -1681,7 +1939,7 @@ int azd_engine_agent_state(azd_engine *e, int agent, uint8_t *parents, uint64_t 
 
 int azd_engine_counters(azd_engine *e, uint64_t *out) {
     if (!e || !out) return AZD_ERR_INVALID_ARGUMENT;
-    AZD_HIP(hipSetDevice(e->cfg.device));
+    AZD_ENTER(e);
     AZD_HIP(hipStreamSynchronize(e->stream));
     const azd::Arenas &a = e->a;
     std::vector<unsigned long long> h((size_t)a.B * azd::NUM_COUNTERS);
@@ -1705,7 +1963,7 @@ int azd_engine_counters(azd_engine *e, uint64_t *out) {
 
 int azd_engine_agent_counters(azd_engine *e, uint64_t *out) {
     if (!e || !out) return AZD_ERR_INVALID_ARGUMENT;
-    AZD_HIP(hipSetDevice(e->cfg.device));
+    AZD_ENTER(e);
     AZD_HIP(hipStreamSynchronize(e->stream));
     AZD_HIP(hipMemcpy(out, e->a.counters, (size_t)e->a.B * azd::NUM_COUNTERS * 8, hipMemcpyDeviceToHost));
     return AZD_OK;
@@ -1842,7 +2100,7 @@ int azd_c21_modify_roots(azd_engine *e, uint64_t seed, uint64_t epoch, int kmin,
                          uint64_t *permitted_out) {
     if (!e || !parents_out || !permitted_out || !e->initialised) return AZD_ERR_INVALID_ARGUMENT;
     if (e->a.space != azd::SPACE_C21 || e->a.path_kind != azd::PATH_SET) return AZD_ERR_UNSUPPORTED;
-    AZD_HIP(hipSetDevice(e->cfg.device));
+    AZD_ENTER(e);
     AZD_HIP(hipStreamSynchronize(e->stream));
     const azd::Arenas &a = e->a;
     const int B = a.B, KW = a.KW, n = a.n;

@@ -262,6 +262,11 @@ struct PoolArgs {
     uint32_t eval_rows;    // rows an evaluator batch may hold: 16, or 32 (two MFMA row tiles per weight fragment)
     uint32_t *post_call;   // [B] FusedEval::kind 4 only: the call whose row the agent has posted (the evaluator hashes it)
     uint32_t debug_abort_call; // test hook (AZD_POOL_DEBUG_ABORT_CALL = k): evaluator workgroup 0 raises PoolCtl::abort after its k-th batch; 0: off
+    // Run-ahead window (azd_engine_run_ahead; the kernel's window instantiation only): the wave that completes a call for the
+    // LAST agent hands the call's argmin candidate to the host while the launch goes on
+    uint32_t *win_count;           // [log_calls] agents through call i (device memory, zero when the launch starts)
+    unsigned long long *win_log;   // [log_calls] pinned host memory: log_key[i] once every agent is through call i
+    uint32_t *win_flag;            // [log_calls] pinned host memory: 1 once win_log[i] is in
 };
 
 // Per-launch values of the CU-resident step forms that are not part of the argument block in device memory (PersistArgs, which
@@ -273,7 +278,8 @@ struct StepLaunch {
     // call ended on a new node whose prediction row / add_actions are still due.  Null: every agent starts at call 0.
     const uint32_t *resume;
     PoolCtl *ctl;                  // pool step: the control block k_argmin_log1 reports the abort flag from and clears; else null
-    int hashed;                    // pool step: FusedEval kind 4, the harness' instantiation of the kernel (k_pool<SP, true>)
+    int hashed;                    // pool step: FusedEval kind 4, the harness' instantiation of the kernel (k_pool<SP, 1>)
+    int window;                    // pool step: publish every completed call to the host (PoolArgs::win_*)
 };
 
 struct PersistArgs { // argument block of the persistent step, read from device memory
@@ -293,6 +299,9 @@ void launch_argmin(const Arenas &a, int init_mode, void *stream);
 // since their last inspection go into log_key[*call_ctr] (atomic min), the counter is bumped; replayed by launch_argmin_log
 void launch_log_candidates(const Arenas &a, unsigned long long *log_key, uint32_t *call_ctr, void *stream);
 void launch_argmin_log(const Arenas &a, int n_calls, unsigned long long *log_key, void *stream);
+// one candidate (agent, node) replayed into the argmin records `a` points at; StatusRec untouched (run-ahead window, engine.hip)
+void launch_argmin_one(const Arenas &a, int agent, uint32_t node, void *stream);
+void ramsey_launch_argmin_one(const Arenas &a, int agent, uint32_t node, void *stream);
 void launch_observe(const Arenas &a, uint32_t n_obs_tol, void *stream);
 bool async_plan(const Arenas &a, const FusedEval &ev, uint32_t *dyn_stride, size_t *dyn_bytes, const char **why = nullptr);
 void launch_async(const Arenas &a, const PersistArgs *d_args, const StepLaunch &sl,

@@ -78,6 +78,13 @@ template <class SP>
 static void l_argmin_log(const Arenas &a, int n_calls, unsigned long long *log_key, hipStream_t st) {
     k_argmin_log1<SP><<<dim3(1), dim3(64), SP::dyn_bytes(a), st>>>(a, n_calls, log_key, nullptr);
 }
+template <class SP>
+static void l_argmin_one(const Arenas &a, int agent, uint32_t node, hipStream_t st) {
+    k_argmin_one<SP><<<dim3(1), dim3(64), SP::dyn_bytes(a), st>>>(a, agent, node);
+}
+void ramsey_launch_argmin_one(const Arenas &a, int agent, uint32_t node, void *stream) {
+    DISPATCH_RKW(a, l_argmin_one, a, agent, node, (hipStream_t)stream);
+}
 void ramsey_launch_argmin_log(const Arenas &a, int n_calls, unsigned long long *log_key, void *stream) {
     DISPATCH_RKW(a, l_argmin_log, a, n_calls, log_key, (hipStream_t)stream);
 }

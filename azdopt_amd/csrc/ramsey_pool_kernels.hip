@@ -27,13 +27,19 @@ namespace azd {
 template <class SP>
 static void l_pool(const Arenas &a, const PersistArgs *d_args, const StepLaunch &sl, const float *params,
                    const void *wpk, int n_blocks, uint32_t dyn_stride, size_t dyn_bytes, hipStream_t st) {
-    if (sl.hashed) {
-        if (hipFuncSetAttribute((const void *)k_pool<SP, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn_bytes) != hipSuccess) return;
-        k_pool<SP, true><<<dim3(n_blocks), dim3(PERSIST_WAVES * 64), dyn_bytes, st>>>(d_args, sl.n_calls, sl.log_key, dyn_stride, params, a.state_vecs, a.h_theta, wpk);
-    } else {
-        if (hipFuncSetAttribute((const void *)k_pool<SP, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn_bytes) != hipSuccess) return;
-        k_pool<SP, false><<<dim3(n_blocks), dim3(PERSIST_WAVES * 64), dyn_bytes, st>>>(d_args, sl.n_calls, sl.log_key, dyn_stride, params, a.state_vecs, a.h_theta, wpk);
+    const int mode = (sl.hashed ? 1 : 0) | (sl.window ? 2 : 0);
+#define AZD_LAUNCH_POOL(M)                                                                                                          \
+    case M:                                                                                                                         \
+        if (hipFuncSetAttribute((const void *)k_pool<SP, M>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn_bytes) != hipSuccess) return; \
+        k_pool<SP, M><<<dim3(n_blocks), dim3(PERSIST_WAVES * 64), dyn_bytes, st>>>(d_args, sl.n_calls, sl.log_key, dyn_stride, params, a.state_vecs, a.h_theta, wpk); \
+        break;
+    switch (mode) {
+        AZD_LAUNCH_POOL(0)
+        AZD_LAUNCH_POOL(1)
+        AZD_LAUNCH_POOL(2)
+        AZD_LAUNCH_POOL(3)
     }
+#undef AZD_LAUNCH_POOL
     k_argmin_log1<SP><<<dim3(1), dim3(64), SP::dyn_bytes(a), st>>>(a, sl.n_calls, sl.log_key, sl.ctl);
 }
 void ramsey_launch_pool(const Arenas &a, const PersistArgs *d_args, const StepLaunch &sl, const float *params,
@@ -43,8 +49,8 @@ void ramsey_launch_pool(const Arenas &a, const PersistArgs *d_args, const StepLa
 template <class SP>
 static void q_pool_resident(int *out, size_t dyn_bytes) {
     int nb = 0;
-    if (hipFuncSetAttribute((const void *)k_pool<SP, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn_bytes) != hipSuccess ||
-        hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, (const void *)k_pool<SP, false>, PERSIST_WAVES * 64, dyn_bytes) != hipSuccess) {
+    if (hipFuncSetAttribute((const void *)k_pool<SP, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn_bytes) != hipSuccess ||
+        hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, (const void *)k_pool<SP, 0>, PERSIST_WAVES * 64, dyn_bytes) != hipSuccess) {
         (void)hipGetLastError();
         nb = 0;
     }

@@ -121,6 +121,15 @@ class NablaOptimizer:
                    "par_roll_out_episodes")
         return imp.value
 
+    def run_ahead(self, n_as_tol, n_calls):
+        """Start the next n_calls calls of par_roll_out_episodes(n_as_tol, ...) now, in one launch; the calls that ask for them --
+        one at a time as in 04-c21-tree.rs:132-160, or in chunks -- launch nothing and are answered as the kernel completes
+        them (azd_engine_run_ahead).  Returns False when this engine's step form cannot do that: the calls then run when asked for."""
+        t, d = self._tol(n_as_tol)
+        ok = C.c_int32()
+        _lib.check(self._L.azd_engine_run_ahead(self._h, _lib.ptr(t), len(t), d, n_calls, C.byref(ok)), "run_ahead")
+        return bool(ok.value)
+
     def par_update_model(self, n_obs_tol):
         """optimizer/mod.rs:249-281"""
         loss = C.c_float()

@@ -5,7 +5,8 @@
 //   examples/c21_tree [epochs 250] [episodes 800] [batch 512] [stride 1] [seed 0] [hidden ... (default 512 1024 512)]
 //
 // Differences forced by the boundary: the `init_states` / `modify_root` closures are the seeded built-ins, and `stride`
-// calls run on the device between two looks at ArgminImprovement (stride 1 = the reference's call-by-call loop).
+// calls are asked for between two looks at ArgminImprovement (stride 1 = the reference's call-by-call loop; the epoch's calls
+// run ahead of the loop in one launch, NablaOptimizer::run_ahead).
 #include <cstdio>
 #include <cstdlib>
 #include <vector>
@@ -54,6 +55,9 @@ int main(int argc, char **argv) {
         const uint32_t n_obs_tol = 200;
         for (int epoch = 1; epoch <= epochs; ++epoch) {
             std::printf("==== EPOCH: %d ====\n", epoch);
+            // the reference asks for its episodes one call at a time (:139-160); the epoch's calls are started in one launch and
+            // the loop below is answered as they complete (a no-op where the engine cannot do that)
+            if (stride < episodes) opt.run_ahead(n_as_tol, episodes);
             for (int done = 0; done < episodes;) {
                 const int k = stride < episodes - done ? stride : episodes - done;
                 const int improved = opt.par_roll_out_episodes(n_as_tol, k);

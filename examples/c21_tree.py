@@ -29,6 +29,7 @@ def main():
     ap.add_argument("--hidden", type=int, nargs="*", default=[512, 1024, 512])  # :42-52
     ap.add_argument("--stride", type=int, default=1)
     ap.add_argument("--seed", type=int, default=0)
+    ap.add_argument("--no-run-ahead", action="store_true", help="one launch per look at ArgminImprovement")
     ap.add_argument("--out", default=None, help="event-file directory (default: tf_path()/04-c21-tree/<time>)")
     args = ap.parse_args()
 
@@ -59,6 +60,10 @@ def main():
     for epoch in range(1, args.epochs + 1):
         print("==== EPOCH: %d ====" % epoch)
         done = 0
+        # the reference asks for its episodes one call at a time (:139-160); the epoch's calls are started in one launch and
+        # the loop below is answered as they complete (NablaOptimizer.run_ahead; a no-op where the engine cannot do that)
+        if args.stride < args.episodes and not args.no_run_ahead:
+            opt.run_ahead(n_as_tol, args.episodes)
         while done < args.episodes:
             k = min(args.stride, args.episodes - done)
             improved = opt.par_roll_out_episodes(n_as_tol, n_calls=k)

@@ -315,6 +315,22 @@ int azd_engine_par_new(azd_engine *e, const uint8_t *parents, const uint64_t *pe
  * returned ArgminImprovement::Improved. */
 int azd_engine_par_roll_out_episodes(azd_engine *e, const uint32_t *n_as_tol, int n_tol,
                                      uint32_t n_as_tol_default, int n_calls, int *improved);
+/* Run-ahead window, for a host that asks for its episodes ONE CALL AT A TIME as the reference's drivers do
+ * (04-c21-tree.rs:132-160: par_roll_out_episodes, then a look at the ArgminImprovement, `episodes` times per epoch): a
+ * launch of the CU-resident step costs ~0.6 ms whatever it holds, so 800 launches of one call run at a fifth of the speed
+ * of one launch of 800.  azd_engine_run_ahead starts the next `n_calls` calls NOW, in one launch, and returns at once;
+ * the azd_engine_par_roll_out_episodes calls that follow (same n_as_tol; one call or any chunk at a time) launch nothing:
+ * each waits until the kernel has published the calls it asks for -- a call is published when its last agent is through it
+ * -- and returns their ArgminImprovements exactly as separate launches would have.  azd_engine_argmin_data (and the Ramsey
+ * form) inside the window return the record as of the calls handed out so far; the winner's replay reads its tree, so they
+ * wait for the launch first.  Any other engine call closes the window: it waits for the launch, and the calls that were not
+ * asked for have run and stay run (counters and trees show them).  The evaluator must not be updated by calls of its own
+ * while a window is open (azd_engine_par_update_model closes it like every engine call).
+ * *accepted = 0 when this engine's step cannot publish calls while it runs (any form but the pool step; n_calls beyond one
+ * launch, 1024; per-launch timing on): nothing is started then and the calls run when they are asked for, so a host may
+ * call this unconditionally. */
+int azd_engine_run_ahead(azd_engine *e, const uint32_t *n_as_tol, int n_tol, uint32_t n_as_tol_default, int n_calls,
+                         int *accepted);
 /* NablaOptimizer::par_update_model (optimizer/mod.rs:249-281) */
 int azd_engine_par_update_model(azd_engine *e, uint32_t n_obs_tol, float *loss);
 /* par_update_model for a population SHARDED over several GPUs (one engine per process and GPU, contiguous agent

@@ -341,6 +341,15 @@ public:
         }
         return improved;
     }
+    // Starts the next n_calls calls of par_roll_out_episodes(n_as_tol, ...) now, in one launch; the calls that ask for them (one at a
+    // time, as in 04-c21-tree.rs:132-160, or in chunks) are answered as the kernel completes them (azd_engine_run_ahead).  False:
+    // this engine's step cannot do that (or the model lives on the host), and the calls run when they are asked for.
+    bool run_ahead(const Tolerance &n_as_tol, int n_calls) {
+        if (host_) return false;
+        int ok = 0;
+        check(azd_engine_run_ahead(h_, n_as_tol.table.data(), (int)n_as_tol.table.size(), n_as_tol.otherwise, n_calls, &ok), "run_ahead");
+        return ok != 0;
+    }
     // optimizer/mod.rs:249-281; returns the loss
     float par_update_model(uint32_t n_obs_tol) {
         float loss = 0.f;

@@ -374,3 +374,111 @@ def test_pool_grid_is_clamped_to_what_the_device_holds(az, monkeypatch):
     form, why = o.step_form()
     assert form == "async" and "resident" in why, (form, why)
     same_engines(o, imp, full[0], full[1], range(0, B, 37))
+
+
+def _window_models(az, kind, B, seed):
+    if kind == "ramsey":
+        space = az.RamseySpaceNoEdgeRecolor(17, [4, 4], [1.0, 1.0])
+        mk = lambda: az.ActionModel(B, space.STATE_DIM, space.ACTION_DIM, hidden=(256, 256), seed=seed)
+        tol = ([200, 200, 100, 100, 50, 50, 25, 25], 10)
+    else:
+        space = az.ROTModifyParentsOnce(19)
+        if kind == "hash":
+            mk = lambda: az.HashStreamModel(space.STATE_DIM, space.ACTION_DIM, seed).serve_from_pool_evaluators()
+        else:
+            mk = lambda: az.ActionModel(B, space.STATE_DIM, space.ACTION_DIM, hidden=(256, 256, 256), seed=seed)
+        tol = TOL_REF
+    return space, mk, tol
+
+
+def _argmin_tuple(a):
+    return (a.eval, a.agent, a.node) + tuple(np.asarray(v).tobytes() for _, v in sorted(a.state.items()))
+
+
+@pytest.mark.parametrize("kind,B", [("hash", 300), ("mlp", 1024), ("ramsey", 256)])
+def test_run_ahead_window_hands_out_the_calls_of_separate_launches(az, orc, kind, B):
+    """azd_engine_run_ahead: n calls in one launch, asked for one at a time -- each call's ArgminImprovement, the argmin record
+    after every improvement, and the trees at the end are those of n launches of one call (hash stream: and of the oracle,
+    call by call)."""
+    seed, calls = 9, 120
+    space, mk, tol = _window_models(az, kind, B, seed)
+    roots = space.generate_roots(seed, B)
+    ref = az.NablaOptimizer.par_new(space, roots, mk(), B, pool_step=True)
+    want, want_rec = [], []
+    for _ in range(calls):
+        want.append(ref.par_roll_out_episodes(tol, n_calls=1))
+        if want[-1]:
+            want_rec.append(_argmin_tuple(ref.argmin_data()))
+    assert ref.step_form() == ("pool", "") and sum(want) > 0
+    opt = az.NablaOptimizer.par_new(space, roots, mk(), B, pool_step=True)
+    assert opt.run_ahead(tol, calls)
+    got, got_rec = [], []
+    for _ in range(calls):
+        got.append(opt.par_roll_out_episodes(tol, n_calls=1))
+        if got[-1]:
+            got_rec.append(_argmin_tuple(opt.argmin_data()))
+    assert got == want
+    assert got_rec == want_rec
+    same_engines(opt, sum(got), ref, sum(want), range(0, B, 7))
+    if kind == "hash":
+        oe = orc.Engine(19, B, threads=8)
+        oe.new_begin(*roots)
+        oe.new_end(orc.hash_predictions(seed, 0, B, space.ACTION_DIM, 0))
+        per_call = []
+        for call in range(1, calls + 1):
+            oe.rollout_begin(*tol)
+            per_call.append(oe.rollout_end(orc.hash_predictions(seed, 0, B, space.ACTION_DIM, call)))
+        assert got == per_call
+    # the window is closed: the next call is a launch of its own, in both engines
+    assert opt.par_roll_out_episodes(tol, n_calls=5) == ref.par_roll_out_episodes(tol, n_calls=5)
+    same_engines(opt, 0, ref, 0, range(0, B, 31))
+
+
+def test_run_ahead_window_in_chunks_closed_early_and_refused(az):
+    """calls asked for in chunks; a window closed by another engine call (the calls not asked for have run); a request the
+    window cannot answer (another tolerance table); an engine whose step cannot publish calls (the hint is refused)"""
+    seed, B, calls = 4, 512, 50
+    space, mk, tol = _window_models(az, "mlp", B, seed)
+    roots = space.generate_roots(seed, B)
+    ref = az.NablaOptimizer.par_new(space, roots, mk(), B, pool_step=True)
+    want = [ref.par_roll_out_episodes(tol, n_calls=1) for _ in range(calls)]
+    opt = az.NablaOptimizer.par_new(space, roots, mk(), B, pool_step=True)
+    assert opt.run_ahead(tol, calls)
+    got = [opt.par_roll_out_episodes(tol, n_calls=7) for _ in range(7)] + [opt.par_roll_out_episodes(tol, n_calls=1)]
+    assert got == [sum(want[i:i + 7]) for i in range(0, 49, 7)] + [want[49]]
+    same_engines(opt, 0, ref, 0, range(0, B, 13))
+    # closed early: 20 of 50 calls asked for, then the counters are read
+    assert opt.run_ahead(tol, calls)
+    want2 = [ref.par_roll_out_episodes(tol, n_calls=1) for _ in range(calls)]
+    got2 = [opt.par_roll_out_episodes(tol, n_calls=1) for _ in range(20)]
+    assert got2 == want2[:20]
+    assert opt.counters()["EXPANSIONS"] == ref.counters()["EXPANSIONS"]  # all 50 have run
+    same_engines(opt, 0, ref, 0, range(0, B, 13))
+    # another tolerance table: the window is closed (its 30 calls have run) and the call runs as a launch of its own
+    assert opt.run_ahead(tol, 30)
+    other = ([100, 20], 5)
+    ref.par_roll_out_episodes(tol, n_calls=30)
+    assert opt.par_roll_out_episodes(other, n_calls=3) == ref.par_roll_out_episodes(other, n_calls=3)
+    same_engines(opt, 0, ref, 0, range(0, B, 13))
+    # the asynchronous step does not publish calls: refused, and the calls run when asked for
+    a1 = az.NablaOptimizer.par_new(space, roots, mk(), B, pool_step=False)
+    assert not a1.run_ahead(tol, calls)
+    assert [a1.par_roll_out_episodes(tol, n_calls=1) for _ in range(calls)] == want
+    assert not opt.run_ahead(tol, 5000)  # more than one launch holds
+
+
+def test_run_ahead_window_survives_an_aborted_launch(az, monkeypatch):
+    """the pool launch behind a window aborts (test hook): the asynchronous step completes its calls; the improvements of the
+    calls it completed are reported together, none is lost, and the state is that of an undisturbed run"""
+    seed, B, calls = 21, 300, 60
+    space, mk, tol = _window_models(az, "mlp", B, seed)
+    roots = space.generate_roots(seed, B)
+    ref = az.NablaOptimizer.par_new(space, roots, mk(), B, pool_step=False)
+    imp_ref = ref.par_roll_out_episodes(tol, n_calls=calls)
+    monkeypatch.setenv("AZD_POOL_DEBUG_ABORT_CALL", "7")
+    opt = az.NablaOptimizer.par_new(space, roots, mk(), B, pool_step=True)
+    assert opt.run_ahead(tol, calls)
+    got = [opt.par_roll_out_episodes(tol, n_calls=1) for _ in range(calls)]
+    form, why = opt.step_form()
+    assert form == "async" and why.startswith("pool step aborted"), (form, why)
+    same_engines(opt, sum(got), ref, imp_ref, range(B))
