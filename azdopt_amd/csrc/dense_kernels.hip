@@ -1,7 +1,8 @@
 // dense_kernels.hip -- dense-graph translation unit of the data-parallel tree-search step on gfx950: tree_core.inc
-// instantiated with the DenseSpace policy (space_dense.inc) for key widths 2 / 4 / 10 / 16, launch-per-phase kernels and the
-// device root policy (the space's state vector,
-// 3E + 1 floats, does not fit the LDS plans of the CU-resident step forms; its evaluator is the batched GEMM).
+// instantiated with the DenseSpace policy (space_dense.inc) for key widths 2 / 4 / 10 / 16: launch-per-phase kernels, the
+// device root policy, and the pool step's searchers (pool_step.inc: k_pool_search) with the evaluator OUTSIDE the kernel --
+// the space's model (3676-512-512-512-2450 at N = 50) does not fit an evaluator workgroup's LDS, its rows are served by
+// batched GEMM launches over what the searchers have posted (k_ext_take / k_ext_deliver).
 // Built with -ffp-contract=off like the other tree units.
 #include <hip/hip_runtime.h>
 
@@ -14,6 +15,11 @@ namespace azd {
 #include "space_dense.inc"
 
 #include "root_policy.inc"
+
+#define AZD_TU_POOL_EXT 1
+#include "persistent_step.inc"
+#include "async_step.inc"
+#include "pool_step.inc"
 
 // the key width (words of a rank set) follows the engine's max_slots: 2, 4, 10 or 16 (engine.hip)
 #define DISPATCH_DKW(A, FN, ...)                                  \
@@ -67,6 +73,70 @@ void dense_launch_observe(const Arenas &a, uint32_t n_obs_tol, void *stream) { D
 void dense_launch_modify_roots(const Arenas &a, uint64_t seed, uint64_t epoch, uint64_t first_agent, int kmin, int kmax,
                                uint8_t *d_adj, uint64_t *d_packed, uint64_t *d_slots, void *stream) {
     DISPATCH_DKW(a, l_modify_roots, a, seed, epoch, first_agent, kmin, kmax, d_adj, d_packed, d_slots, (hipStream_t)stream);
+}
+
+
+// ---------------------------------------------------------------- pool step, searchers only
+// LDS of a searcher workgroup: 16 waves' blocks and scratch regions (no row is staged: SP::write_rows_direct)
+template <class SP>
+static void q_pool_plan(const Arenas &a, uint32_t *dyn_stride, size_t *dyn_bytes) {
+    const size_t stride = (SP::dyn_bytes(a) + 15) & ~(size_t)15;
+    const size_t sw_bytes = (PERSIST_WAVES * sizeof(typename SP::Lds) + 15) & ~(size_t)15;
+    *dyn_stride = (uint32_t)stride;
+    *dyn_bytes = sw_bytes + stride * PERSIST_WAVES;
+}
+bool dense_pool_plan(const Arenas &a, uint32_t *dyn_stride, size_t *dyn_bytes, const char **why) {
+    if (a.B > 65536 || a.node_cap > 65536) {
+        *why = "pool step: more than 65536 agents or nodes per tree";
+        return false;
+    }
+    DISPATCH_DKW(a, q_pool_plan, a, dyn_stride, dyn_bytes);
+    if (*dyn_bytes + sizeof(PoolIdle) + 256 > 160 * 1024) {
+        *why = "pool step: 16 searcher waves' blocks and scratch do not fit the CU's 160 KB of LDS (more than 640 slots per root)";
+        return false;
+    }
+    return true;
+}
+template <class SP>
+static void l_pool_search(const Arenas &a, const PersistArgs *d_args, const StepLaunch &sl, int n_blocks, uint32_t dyn_stride, size_t dyn_bytes,
+                          hipStream_t st) {
+    if (sl.hashed) { // the test harness' evaluator (FusedEval kind 4): the searchers note the call of every row they post
+        if (hipFuncSetAttribute((const void *)k_pool_search<SP, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn_bytes) != hipSuccess) return;
+        k_pool_search<SP, 1><<<dim3(n_blocks), dim3(PERSIST_WAVES * 64), dyn_bytes, st>>>(d_args, sl.n_calls, sl.log_key, dyn_stride);
+    } else {
+        if (hipFuncSetAttribute((const void *)k_pool_search<SP, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn_bytes) != hipSuccess) return;
+        k_pool_search<SP, 0><<<dim3(n_blocks), dim3(PERSIST_WAVES * 64), dyn_bytes, st>>>(d_args, sl.n_calls, sl.log_key, dyn_stride);
+    }
+    k_argmin_log1<SP><<<dim3(1), dim3(64), SP::dyn_bytes(a), st>>>(a, sl.n_calls, sl.log_key, sl.ctl);
+}
+void dense_launch_pool_search(const Arenas &a, const PersistArgs *d_args, const StepLaunch &sl, int n_blocks, uint32_t dyn_stride,
+                              size_t dyn_bytes, void *stream) {
+    DISPATCH_DKW(a, l_pool_search, a, d_args, sl, n_blocks, dyn_stride, dyn_bytes, (hipStream_t)stream);
+}
+template <class SP>
+static void q_pool_search_resident(int *out, size_t dyn_bytes) {
+    int nb = 0;
+    if (hipFuncSetAttribute((const void *)k_pool_search<SP, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn_bytes) != hipSuccess ||
+        hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, (const void *)k_pool_search<SP, 0>, PERSIST_WAVES * 64, dyn_bytes) != hipSuccess) {
+        (void)hipGetLastError();
+        nb = 0;
+    }
+    *out = nb;
+}
+int dense_pool_search_resident(const Arenas &a, size_t dyn_bytes) { // workgroups of k_pool_search one CU holds
+    int nb = 0;
+    DISPATCH_DKW(a, q_pool_search_resident, &nb, dyn_bytes);
+    return nb;
+}
+void launch_ext_take(const PoolArgs &pool, uint32_t *rows, uint32_t *home, uint32_t *n, uint32_t cap, void *stream) {
+    k_ext_take<<<dim3(1), dim3(POOL_XCDS * 64), 0, (hipStream_t)stream>>>(pool, rows, home, n, cap);
+}
+void launch_ext_hash_rows(const PersistArgs *d_args, const uint32_t *rows, const uint32_t *n, uint32_t cap, float *h_theta, void *stream) {
+    k_ext_hash_rows<<<dim3(cap), dim3(256), 0, (hipStream_t)stream>>>(d_args, rows, n, h_theta);
+}
+void launch_ext_deliver(const PoolArgs &pool, const Arenas &a, const uint32_t *rows, const uint32_t *home, const uint32_t *n, uint32_t cap,
+                        void *stream) {
+    k_ext_deliver<<<dim3((cap + 255) / 256), dim3(256), 0, (hipStream_t)stream>>>(pool, a, rows, home, n);
 }
 
 } // namespace azd

@@ -158,6 +158,16 @@ struct azd_engine {
     hipGraphExec_t sub_graph[MAX_SUBS] = {};
     int sub_graph_n = 0;
     uint32_t *d_call_ctr = nullptr; // [MAX_SUBS] calls a sub-population has logged in the current run
+    // pool step with the evaluator outside the kernel (dense-graph space): the searchers run on `stream`, the host replays a graph of
+    // [collect the posted rows, the model's GEMMs over them, hand the agents back] on ext_stream until the searchers are through
+    hipStream_t ext_stream = nullptr;
+    hipGraphExec_t ext_graph = nullptr;
+    uint64_t ext_graph_layout = 0;
+    bool ext_unsupported = false;     // the evaluator cannot serve gathered rows from device-side lists (asked once)
+    uint32_t *d_ext_rows = nullptr, *d_ext_home = nullptr, *d_ext_n = nullptr;
+    static constexpr int EXT_IN_FLIGHT = 2;
+    hipEvent_t ext_done = nullptr, ext_fork = nullptr, ext_ring[EXT_IN_FLIGHT] = {};
+    unsigned long long ext_iterations = 0; // evaluator graph replays of the last dense pool launch (diagnostics)
     // dense-graph space: host-visible key width (action-id sets) and the packed roots as the device wants them
     int kw_host = 0;
     int dense_slots = 0;              // 64 * a.KW: the most modifiable slots a root may bring
@@ -786,6 +796,11 @@ int azd_engine_create(azd_engine **out, const azd_engine_config *cfg, azd_evalua
         TRY(e->alloc(&e->pool.post_call, B));
         TRY(e->alloc(&e->d_resume, B));
         TRY(e->alloc(&e->d_call_ctr, (size_t)azd_engine::MAX_SUBS));
+        if (dense) {
+            TRY(e->alloc(&e->d_ext_rows, B));
+            TRY(e->alloc(&e->d_ext_home, B));
+            TRY(e->alloc(&e->d_ext_n, 1));
+        }
     }
     e->log_calls = 1024;
     {
@@ -860,6 +875,12 @@ int azd_engine_destroy(azd_engine *e) {
         if (e->sub_stream[i]) (void)hipStreamDestroy(e->sub_stream[i]);
     }
     if (e->sub_fork) (void)hipEventDestroy(e->sub_fork);
+    if (e->ext_graph) (void)hipGraphExecDestroy(e->ext_graph);
+    if (e->ext_done) (void)hipEventDestroy(e->ext_done);
+    if (e->ext_fork) (void)hipEventDestroy(e->ext_fork);
+    for (int i = 0; i < azd_engine::EXT_IN_FLIGHT; ++i)
+        if (e->ext_ring[i]) (void)hipEventDestroy(e->ext_ring[i]);
+    if (e->ext_stream) (void)hipStreamDestroy(e->ext_stream);
     for (auto &it : e->ev_inflight) {
         (void)hipEventDestroy(it.second.first);
         (void)hipEventDestroy(it.second.second);
@@ -992,11 +1013,187 @@ static int pool_finish_launch(azd_engine *e, const azd::FusedEval &fe, const azd
     return AZD_OK;
 }
 
+// The pool step of the dense-graph space (BASELINE configs[4]): searcher workgroups only (k_pool_search) on part of the chip; the
+// model -- too large for an evaluator workgroup's LDS -- is served by batched GEMM launches over the rows the searchers have posted,
+// replayed from a graph on a second stream for as long as the searchers run.  Agents advance independently, so a launch no longer
+// lasts as long as its slowest agent per call (launch-per-phase form: a roll-out launch took 1.2 ms where the mean agent needed 0.06).
+// *ran = false: the form cannot run here (why in e->step_reason) and the caller takes the launch-per-phase form.
+static int dense_pool_run(azd_engine *e, const azd::TolTable &t, int n_calls, bool *ran) {
+    *ran = false;
+    const azd::Arenas &a = e->a;
+    const char *why = "";
+    uint32_t dyn_stride = 0;
+    size_t dyn_bytes = 0;
+    azd::FusedEval fe;
+    const bool hashed = e->ev->fused_desc(&fe) && fe.kind == 4; // the test harness' fixed prediction stream, served like a model's rows
+    if (!e->pool_step || !e->persist_enabled || e->pool_failed || e->ext_unsupported || a.KW > 4 || (!a.state_vecs16 && !hashed) ||
+        n_calls < 1 || !azd::dense_pool_plan(a, &dyn_stride, &dyn_bytes, &why)) {
+        e->step_reason = !e->pool_step || !e->persist_enabled ? "dense-graph space: the pool step is not configured for this engine"
+                         : e->pool_failed                      ? "an earlier pool launch of this engine aborted: launch-per-phase form"
+                         : a.KW > 4                            ? "dense-graph space: the pool step's searchers hold up to 256 slots per root (register budget of a 16-wave workgroup)"
+                         : ((!a.state_vecs16 && !hashed) || e->ext_unsupported)
+                             ? "dense-graph space: the pool step needs an evaluator that serves gathered bf16 rows (ActionModel with bf16 storage)"
+                             : why;
+        return AZD_OK;
+    }
+    const int per_cu = azd::dense_pool_search_resident(a, dyn_bytes);
+    // searcher workgroups: no more waves than twice the agents, and no more than half the chip -- the GEMM launches need the rest
+    int n_search = (a.B + 7) / 8;
+    if (n_search > e->n_cus / 2) n_search = e->n_cus / 2;
+    if (const char *env = getenv("AZD_DENSE_POOL_SEARCH_WGS")) n_search = atoi(env) > 0 ? atoi(env) : n_search;
+    if (per_cu < 1 || n_search > e->n_cus * 7 / 8) n_search = per_cu < 1 ? 0 : e->n_cus * 7 / 8;
+    if (n_search < 1) {
+        e->step_reason = "dense-graph space: the device holds no searcher workgroup of the pool step";
+        return AZD_OK;
+    }
+    if (!e->ext_stream) AZD_HIP(hipStreamCreateWithFlags(&e->ext_stream, hipStreamNonBlocking));
+    if (!e->ext_done) AZD_HIP(hipEventCreateWithFlags(&e->ext_done, hipEventDisableTiming));
+    if (!e->ext_fork) AZD_HIP(hipEventCreateWithFlags(&e->ext_fork, hipEventDisableTiming));
+    for (int i = 0; i < azd_engine::EXT_IN_FLIGHT; ++i)
+        if (!e->ext_ring[i]) AZD_HIP(hipEventCreateWithFlags(&e->ext_ring[i], hipEventDisableTiming));
+    azd::PoolArgs pool = e->pool;
+    pool.n_eval = 0;
+    pool.ready_lanes = 0;
+    pool.n_express = 0;
+    pool.express_waves = 0;
+    pool.express_shift = 0;
+    pool.early_post = 1; // the request leaves with the row: the GEMMs run while the wave computes lambda_1 and the matching
+    if (const char *env = getenv("AZD_POOL_EARLY_POST")) pool.early_post = atoi(env);
+    pool.eval_stride = pool.eval_out_off = 0;
+    pool.eval_rows = 0;
+    pool.debug_abort_call = 0;
+    // the evaluator's graph: collect, the layers over the collected rows, hand back
+    if (!e->ext_graph || e->ext_graph_layout != e->ev->layout_version + (hashed ? 1ull << 63 : 0ull)) {
+        if (e->ext_graph) (void)hipGraphExecDestroy(e->ext_graph);
+        e->ext_graph = nullptr;
+        hipGraph_t g = nullptr;
+        AZD_HIP(hipStreamBeginCapture(e->ext_stream, hipStreamCaptureModeThreadLocal));
+        azd::launch_ext_take(pool, e->d_ext_rows, e->d_ext_home, e->d_ext_n, (uint32_t)a.B, e->ext_stream);
+        int st_g = AZD_OK;
+        if (hashed) azd::launch_ext_hash_rows(e->d_pargs, e->d_ext_rows, e->d_ext_n, (uint32_t)a.B, a.h_theta, e->ext_stream);
+        else st_g = e->ev->write_predictions_gathered(e->d_ext_rows, e->d_ext_n, a.B, a.state_vecs16, a.S16, a.h_theta, e->ext_stream);
+        azd::launch_ext_deliver(pool, a, e->d_ext_rows, e->d_ext_home, e->d_ext_n, (uint32_t)a.B, e->ext_stream);
+        const hipError_t he = hipStreamEndCapture(e->ext_stream, &g);
+        if (st_g) {
+            if (g) (void)hipGraphDestroy(g);
+            if (st_g != AZD_ERR_UNSUPPORTED) return st_g;
+            e->ext_unsupported = true;
+            e->step_reason = "dense-graph space: the pool step needs an evaluator that serves gathered bf16 rows (ActionModel with bf16 storage)";
+            return AZD_OK;
+        }
+        if (he != hipSuccess) return azd::hip_fail(he, "hipStreamEndCapture");
+        const hipError_t hi = hipGraphInstantiate(&e->ext_graph, g, nullptr, nullptr, 0);
+        (void)hipGraphDestroy(g);
+        if (hi != hipSuccess) return azd::hip_fail(hi, "hipGraphInstantiate");
+        e->ext_graph_layout = e->ev->layout_version + (hashed ? 1ull << 63 : 0ull);
+    }
+    if (!hashed) {
+        memset(&fe, 0, sizeof(fe));
+        fe.kind = 3; // what the searchers look at: requests are posted for an evaluator
+    }
+    e->step_form = AZD_STEP_POOL;
+    e->step_reason.clear();
+    e->pool_eval_wgs = 0;
+    e->pool_search_wgs = n_search;
+    e->pool_search_waves = n_search * 16;
+    e->ext_iterations = 0;
+    int left = n_calls;
+    while (left > 0) {
+        const int k = left < e->log_calls ? left : e->log_calls;
+        {   // the argument block (re-sent only when it changed)
+            azd::PersistArgs now;
+            memset(&now, 0, sizeof(now));
+            now.a = a;
+            now.tol = t;
+            now.ev = fe;
+            now.ev.call_base = hashed ? e->ev->calls : 0; // hash stream: index of the launch's first call
+            now.pool = pool;
+            if (!e->pargs_valid || memcmp(&e->pargs_sent, &now, sizeof(now)) != 0) {
+                AZD_HIP(hipStreamSynchronize(e->stream));
+                memcpy(e->h_pargs, &now, sizeof(now));
+                AZD_HIP(hipMemcpyAsync(e->d_pargs, e->h_pargs, sizeof(azd::PersistArgs), hipMemcpyHostToDevice, e->stream));
+                memcpy(&e->pargs_sent, &now, sizeof(now));
+                e->pargs_valid = true;
+            }
+        }
+        int st = pool_clear(e, pool); // (always: a collect that ran past the end of the last launch may have touched the control block)
+        if (st) return st;
+        if (!e->log_clean) {
+            AZD_HIP(hipMemsetAsync(e->d_log_key, 0xFF, (size_t)e->log_calls * sizeof(unsigned long long), e->stream));
+            e->log_clean = true;
+        }
+        AZD_HIP(hipMemsetAsync(e->d_ext_n, 0, sizeof(uint32_t), e->stream));
+        AZD_HIP(hipEventRecord(e->ext_fork, e->stream));
+        AZD_HIP(hipStreamWaitEvent(e->ext_stream, e->ext_fork, 0)); // the evaluator's first collect sees the cleared queues
+        azd::StepLaunch sl;
+        sl.n_calls = k;
+        sl.log_key = e->d_log_key;
+        sl.resume = nullptr;
+        sl.ctl = pool.ctl;
+        sl.hashed = hashed ? 1 : 0;
+        sl.window = 0;
+        e->time_begin(0);
+        azd::dense_launch_pool_search(a, e->d_pargs, sl, n_search, dyn_stride, dyn_bytes, e->stream);
+        e->time_end();
+        AZD_HIP(hipGetLastError());
+        AZD_HIP(hipEventRecord(e->ext_done, e->stream));
+        e->pool_clean = false;
+        // the evaluator: replayed until the searchers (and the argmin replay behind them) are through, EXT_IN_FLIGHT replays queued
+        // at a time -- a replay that finds nothing posted costs a few microseconds
+        unsigned long long it = 0;
+        for (;;) {
+            const hipError_t q = hipEventQuery(e->ext_done);
+            if (q == hipSuccess) break;
+            if (q != hipErrorNotReady) return azd::hip_fail(q, "hipEventQuery");
+            hipEvent_t slot = e->ext_ring[it % azd_engine::EXT_IN_FLIGHT];
+            if (it >= (unsigned long long)azd_engine::EXT_IN_FLIGHT) AZD_HIP(hipEventSynchronize(slot));
+            AZD_HIP(hipGraphLaunch(e->ext_graph, e->ext_stream));
+            AZD_HIP(hipEventRecord(slot, e->ext_stream));
+            it += 1;
+        }
+        AZD_HIP(hipStreamSynchronize(e->ext_stream));
+        e->ext_iterations += it;
+        left -= k;
+        e->ev->calls += (uint64_t)k;
+        st = fetch_status(e);
+        if (st) return st;
+        if (e->h_status->pool_ticks > 0) {
+            const double T = (double)e->h_status->pool_ticks;
+            e->pool_util_eval = 0.0;
+            e->pool_util_search = (double)e->h_status->pool_search_busy / (T * e->pool_search_waves);
+        }
+        if (e->h_status->pool_abort) {
+            // no other CU-resident form exists for this space to take the launch over; the trees stand between calls, but
+            // agents have made different numbers of them
+            e->pool_failed = true;
+            e->log_clean = false;
+            azd::g_last_error = "dense pool step: a queue wait ran into its bound (no searcher or evaluator launch made progress); "
+                                "this engine takes the launch-per-phase form from here on";
+            return AZD_ERR_UNREACHABLE;
+        }
+    }
+    *ran = true;
+    return AZD_OK;
+}
+
 // optimizer/mod.rs:159-190, n_calls times.  ahead: azd_engine_run_ahead -- the launch is left running and its calls are handed
 // out by window_serve; *accepted = 0 when this engine's step form cannot do that (nothing is launched then).
 static int roll_out_impl(azd_engine *e, const azd::TolTable &t, int n_calls, int *improved, bool ahead, int *accepted) {
     int st = AZD_OK;
     if (accepted) *accepted = 0;
+    if (e->a.space == azd::SPACE_DENSE && !getenv("AZD_DENSE_NO_POOL")) {
+        if (ahead) return AZD_OK; // (the evaluator's launches need this thread: nothing can run ahead of the host)
+        bool ran = false;
+        st = dense_pool_run(e, t, n_calls, &ran);
+        if (st) return st;
+        if (ran) {
+            st = check_status(e);
+            if (improved) *improved = (int)(e->h_status->improved - e->seen_improved);
+            e->seen_improved = e->h_status->improved;
+            return st;
+        }
+    }
+    const std::string dense_reason = e->a.space == azd::SPACE_DENSE ? e->step_reason : std::string();
     azd::FusedEval fe;
     uint32_t dyn_stride = 0;
     size_t dyn_bytes = 0;
@@ -1136,6 +1333,7 @@ static int roll_out_impl(azd_engine *e, const azd::TolTable &t, int n_calls, int
         if (!use_async && !use_barrier && *why_b) e->step_reason += std::string("; ") + why_b;
     }
     e->step_form = use_pool ? AZD_STEP_POOL : use_async ? AZD_STEP_ASYNC : use_barrier ? AZD_STEP_BARRIER : AZD_STEP_PER_CALL;
+    if (!dense_reason.empty()) e->step_reason = dense_reason; // (why the space's pool step did not run: the launch-per-phase form follows)
     if (ahead) { // only the pool step publishes its calls while it runs, one launch's worth of them
         const bool ok = use_pool && fe.kind >= 3 && n_calls >= 1 && n_calls <= e->log_calls && !e->timing;
         if (!ok) return AZD_OK; // a hint: the calls run when they are asked for

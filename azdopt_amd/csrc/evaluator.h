@@ -52,6 +52,13 @@ struct azd_evaluator {
                                        d_p + (size_t)row0 * action_dim, st);
     }
     virtual bool rows_concurrent() { return false; }
+    // The pool step's evaluator outside the kernel (engine.hip, dense-graph space): predictions for the *d_count (<= max_rows) rows
+    // whose indices stand in d_rows -- inputs d_s16[row], outputs d_p[row] -- with everything the launches need in device memory,
+    // so that the sequence can be captured once and replayed.  AZD_ERR_UNSUPPORTED: this evaluator cannot (the engine asks once).
+    virtual int write_predictions_gathered(const uint32_t * /*d_rows*/, const uint32_t * /*d_count*/, int /*max_rows*/, const uint16_t * /*d_s16*/,
+                                           int /*pitch16*/, float * /*d_p*/, hipStream_t /*st*/) {
+        return AZD_ERR_UNSUPPORTED;
+    }
     // description for the persistent step (evaluator inside the kernel); false = not fusable
     virtual bool fused_desc(azd::FusedEval *) { return false; }
     // write_predictions_dev(batch) launches the same kernels with the same arguments on every call and allocates nothing

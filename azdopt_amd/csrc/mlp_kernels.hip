@@ -604,6 +604,24 @@ struct MlpEvaluator : azd_evaluator {
         return forward16(count, d_s + (size_t)row0 * state_dim, x16, d_p + (size_t)row0 * action_dim, st, row0);
     }
     bool rows_concurrent() override { return bf16 && d_w16p && !getenv("AZD_GEMM_OLD"); }
+    int write_predictions_gathered(const uint32_t *d_rows, const uint32_t *d_count, int max_rows, const uint16_t *d_s16, int pitch16, float *d_p,
+                                   hipStream_t st) override {
+        if (!rows_concurrent() || !d_s16 || pitch16 != kp[0]) return AZD_ERR_UNSUPPORTED;
+        AZD_HIP(hipSetDevice(device));
+        int s = ensure_batch(max_rows);
+        if (s) return s;
+        const uint16_t *x16 = d_s16;
+        for (int l = 0; l < L; ++l) {
+            const bool last = l == L - 1;
+            void *y = last ? (void *)d_p : (void *)d_act16[(size_t)l + 1];
+            launch_gemm16_ext(st, x16, kp[(size_t)l], d_w16p + wp_off[(size_t)l], kp[(size_t)l], y, last ? dims[(size_t)L] : kp[(size_t)l + 1], max_rows,
+                              dims[(size_t)l + 1], kp[(size_t)l], last ? final_act : AZD_ACT_RELU, last ? 0 : 1, d_params + b_off[(size_t)l], n_cus, d_count,
+                              l == 0 ? d_rows : nullptr, last ? d_rows : nullptr);
+            if (!last) x16 = d_act16[(size_t)l + 1];
+        }
+        AZD_HIP(hipGetLastError());
+        return AZD_OK;
+    }
 
     // dfdx.rs:86-131
     int update_model_dev(int batch, const float *d_s, const float *d_o, const float *d_w, float *loss, hipStream_t st) override {

@@ -349,9 +349,10 @@ def main():
         avg_ms = timing["rollout_ms"] / launches
         bytes_per_launch = bytes_per_exp * exp_for_roofline / launches
         achieved = bytes_per_launch / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
-        kw = 2 if wl["kind"] == "dense" else kw  # device keys of the dense space: ranks of the root's modifiable slots
+        if wl["kind"] == "dense":  # device keys of the dense space: ranks of the root's modifiable slots, 64 per word
+            kw = next(w for w, cap in ((2, 128), (4, 256), (10, 640), (16, 1024)) if space.MAX_SLOTS <= cap)
         kernel = {"async": "k_async<%d>", "barrier": "k_persist<%d>", "per_call": "k_rollout<%d>", "per_call_graph": "k_rollout<%d>",
-                  "pool": "k_pool<%d>"}.get(form, "?<%d>") % kw
+                  "pool": "k_pool_search<%d>" if wl["kind"] == "dense" else "k_pool<%d>"}.get(form, "?<%d>") % kw
         # HBM traffic is not measured by this process (PMC counters need rocprofv3): it is the per-call figure of the
         # committed profile of the same kernel and workload, scaled to this run's calls per launch, or null
         traffic, traffic_src = None, None
@@ -409,6 +410,9 @@ def main():
                 "bytes_per_rank_each": 4 * B * (space.STATE_DIM + 2 * space.ACTION_DIM),
                 "note": "native: one call = all-gather + optimiser step; torch: the all-gather alone"},
             "step_form": form, "step_form_reason": form_why, "pool_split": list(opt.pool_split()) if form == "pool" else None,
+            "evaluator_form": ("outside the kernel: batched bf16 GEMM launches over the rows the searchers have posted, replayed from a hipGraph "
+                               "on a second stream while the searchers run") if (form == "pool" and wl["kind"] == "dense") else
+                              ("evaluator workgroups inside the kernel" if form == "pool" else None),
             "epoch_boundary_in_timed_region": n_bound > 0, "epoch_boundaries_in_timed_region": n_bound,
             "best_cost_found": best_cost, "best_eval": best_eval,
             "expansions": exp_total, "terminals": d["TERMINALS"], "transpositions": d["TRANSPOSITIONS"],

@@ -31,11 +31,16 @@ def compare(opt, oe, agents, tag):
     assert np.array_equal(ag.state["adj"].view(np.uint8), ao["parents"]) and np.array_equal(ag.state["permitted"], ao["permitted"]), tag
 
 
-def run_dense_parity(az, orc, n, B, p, kmin, kmax, tol, steps, epochs, seed, check_every, max_slots=128, policy=False, **caps):
+def run_dense_parity(az, orc, n, B, p, kmin, kmax, tol, steps, epochs, seed, check_every, max_slots=128, policy=False, pool=False, **caps):
     """policy: the epoch boundary is the drivers' modify_root on the DEVICE (par_reset_trees_policy: node choice in key
-    order, path replay, fresh connected roots, re-drawn slots) against the oracle's, instead of fresh roots from the host"""
+    order, path replay, fresh connected roots, re-drawn slots) against the oracle's, instead of fresh roots from the host.
+    pool: the space's pool step (k_pool_search: agents multiplexed over searcher waves, running ahead of each other) with the
+    fixed prediction stream served like a model's rows: collected, computed and handed back by launches on a second stream"""
     space = az.DenseGraphSpace(n, p, max_slots=max_slots)
     model = az.HashStreamModel(space.STATE_DIM, space.ACTION_DIM, seed)
+    if pool:
+        model = model.serve_from_pool_evaluators()
+        caps = dict(caps, pool_step=True)
     roots = space.generate_roots(seed, B, kmin=kmin, kmax=kmax)
     opt = az.NablaOptimizer.par_new(space, roots, model, B, **caps)
     oe = orc.Engine(n, B, threads=8, dense=True, dense_p=p)
@@ -56,7 +61,12 @@ def run_dense_parity(az, orc, n, B, p, kmin, kmax, tol, steps, epochs, seed, che
             assert ig == io
             s += k
             compare(opt, oe, range(B), f"epoch {epoch} step {s}")
-        assert opt.step_form()[0] == "per_call" and "dense-graph space" in opt.step_form()[1]
+        if pool:
+            assert opt.step_form() == ("pool", "")
+            c = opt.counters()
+            assert c["EVAL_ROWS"] == c["EXPANSIONS"] > 0  # every row went through the evaluator's launches
+        else:
+            assert opt.step_form()[0] == "per_call" and "dense-graph space" in opt.step_form()[1]
         sv, obs, w = opt.observe(2)
         oo, ow = oe.observe(2)
         assert np.array_equal(obs.view(np.uint32), oo.view(np.uint32)) and np.array_equal(w, ow) and np.array_equal(sv, oe.state_vecs())
@@ -89,6 +99,54 @@ def test_dense_parity_n50_reference_tolerances(az, orc):
     """BASELINE configs[4]'s N = 50 (E = 1225, ACTION 2450, STATE 3676) with up to 128 modifiable slots per root"""
     c = run_dense_parity(az, orc, 50, 32, 0.1, 5, 128, ([200, 50, 50], 25), steps=100, epochs=1, seed=1, check_every=50)
     assert c["EXPANSIONS"] > 2000 and c["MAX_DEPTH"] >= 3
+
+
+@pytest.mark.parametrize("n,B,p,kmin,kmax,tol,steps,every,slots", [
+    (8, 12, 0.4, 2, 10, ([6, 3], 2), 40, 1, 128),
+    (20, 300, 0.2, 5, 60, ([50, 20, 10], 5), 120, 40, 128),
+    (50, 96, 0.1, 5, 128, ([200, 50, 50], 25), 100, 50, 128),
+    (50, 40, 0.1, 150, 250, ([200, 50, 50], 25), 60, 30, 256),
+])
+def test_dense_pool_step_against_the_oracle(az, orc, n, B, p, kmin, kmax, tol, steps, every, slots):
+    """the space's CU-resident form: searcher workgroups only, the evaluator outside the kernel.  Trees, state vectors, costs,
+    counters, argmin, observations and the device root policy against the oracle, as for the launch-per-phase form"""
+    c = run_dense_parity(az, orc, n, B, p, kmin, kmax, tol, steps=steps, epochs=2, seed=7, check_every=every, max_slots=slots, policy=True, pool=True)
+    assert c["EXPANSIONS"] > 100
+
+
+def test_dense_pool_step_with_the_bf16_model_equals_the_launch_per_phase_form(az, monkeypatch):
+    """config E's model on the pool step: the rows the searchers post are gathered into the batched bf16 GEMMs (k_gemm16 with row
+    lists, whatever batch a row lands in) and scattered back -- same trees, counters, argmin, prediction rows and training step
+    as one launch per phase"""
+    n, B, seed, calls = 50, 640, 5, 70
+    tol = ([200, 50, 50], 25)
+    space = az.DenseGraphSpace(n, 0.1)
+    roots = space.generate_roots(seed, B)
+    runs = []
+    for pool in (True, False):
+        if not pool:
+            monkeypatch.setenv("AZD_DENSE_NO_POOL", "1")
+        model = az.ActionModel(B, space.STATE_DIM, space.ACTION_DIM, hidden=(512, 512, 512), seed=seed, dtype="bf16")
+        o = az.NablaOptimizer.par_new(space, roots, model, B)
+        imp = o.par_roll_out_episodes(tol, n_calls=calls)
+        assert o.step_form()[0] == ("pool" if pool else "per_call_graph"), o.step_form()
+        loss = o.par_update_model(3)
+        o.par_reset_trees_policy(seed, 0, 5, 128)
+        imp2 = o.par_roll_out_episodes(tol, n_calls=30)
+        runs.append((o, imp, imp2, loss))
+    monkeypatch.delenv("AZD_DENSE_NO_POOL")
+    (o0, i0, j0, l0), (o1, i1, j1, l1) = runs
+    assert (i0, j0) == (i1, j1) and l0 == l1
+    c0, c1 = o0.counters(), o1.counters()
+    for k in MAIN_CTRS:
+        assert c0[k] == c1[k], k
+    assert c0["EVAL_ROWS"] == c0["EXPANSIONS"]
+    for i in range(0, B, 5):
+        assert_tree_equal(o0.get_tree(i), o1.get_tree(i), f"agent {i}")
+    a0, a1 = o0.argmin_data(), o1.argmin_data()
+    assert a0.eval == a1.eval and a0.agent == a1.agent and a0.node == a1.node
+    assert np.array_equal(o0.state_vecs(), o1.state_vecs())
+    assert np.array_equal(o0.predictions().view(np.uint32), o1.predictions().view(np.uint32))
 
 
 def test_dense_roots_are_validated(az):
