@@ -79,18 +79,19 @@ void dense_launch_modify_roots(const Arenas &a, uint64_t seed, uint64_t epoch, u
 // ---------------------------------------------------------------- pool step, searchers only
 // LDS of a searcher workgroup: 16 waves' blocks and scratch regions (no row is staged: SP::write_rows_direct)
 template <class SP>
-static void q_pool_plan(const Arenas &a, uint32_t *dyn_stride, size_t *dyn_bytes) {
+static void q_pool_plan(const Arenas &a, int waves, uint32_t *dyn_stride, size_t *dyn_bytes) {
     const size_t stride = (SP::dyn_bytes(a) + 15) & ~(size_t)15;
-    const size_t sw_bytes = (PERSIST_WAVES * sizeof(typename SP::Lds) + 15) & ~(size_t)15;
+    const size_t sw_bytes = (PERSIST_WAVES * sizeof(typename SP::Lds) + 15) & ~(size_t)15; // (k_pool_search's SW_BYTES: the layout of 16 waves' blocks)
     *dyn_stride = (uint32_t)stride;
-    *dyn_bytes = sw_bytes + stride * PERSIST_WAVES;
+    *dyn_bytes = sw_bytes + stride * (size_t)waves;
 }
-bool dense_pool_plan(const Arenas &a, uint32_t *dyn_stride, size_t *dyn_bytes, const char **why) {
+// waves: wavefronts per searcher workgroup (1 .. 16): fewer leave registers and LDS on the CU for the evaluator's GEMM blocks
+bool dense_pool_plan(const Arenas &a, int waves, uint32_t *dyn_stride, size_t *dyn_bytes, const char **why) {
     if (a.B > 65536 || a.node_cap > 65536) {
         *why = "pool step: more than 65536 agents or nodes per tree";
         return false;
     }
-    DISPATCH_DKW(a, q_pool_plan, a, dyn_stride, dyn_bytes);
+    DISPATCH_DKW(a, q_pool_plan, a, waves, dyn_stride, dyn_bytes);
     if (*dyn_bytes + sizeof(PoolIdle) + 256 > 160 * 1024) {
         *why = "pool step: 16 searcher waves' blocks and scratch do not fit the CU's 160 KB of LDS (more than 640 slots per root)";
         return false;
@@ -98,38 +99,38 @@ bool dense_pool_plan(const Arenas &a, uint32_t *dyn_stride, size_t *dyn_bytes, c
     return true;
 }
 template <class SP>
-static void l_pool_search(const Arenas &a, const PersistArgs *d_args, const StepLaunch &sl, int n_blocks, uint32_t dyn_stride, size_t dyn_bytes,
-                          hipStream_t st) {
+static void l_pool_search(const Arenas &a, const PersistArgs *d_args, const StepLaunch &sl, int n_blocks, int waves, uint32_t dyn_stride,
+                          size_t dyn_bytes, hipStream_t st) {
     if (sl.hashed) { // the test harness' evaluator (FusedEval kind 4): the searchers note the call of every row they post
         if (hipFuncSetAttribute((const void *)k_pool_search<SP, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn_bytes) != hipSuccess) return;
-        k_pool_search<SP, 1><<<dim3(n_blocks), dim3(PERSIST_WAVES * 64), dyn_bytes, st>>>(d_args, sl.n_calls, sl.log_key, dyn_stride);
+        k_pool_search<SP, 1><<<dim3(n_blocks), dim3(waves * 64), dyn_bytes, st>>>(d_args, sl.n_calls, sl.log_key, dyn_stride);
     } else {
         if (hipFuncSetAttribute((const void *)k_pool_search<SP, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn_bytes) != hipSuccess) return;
-        k_pool_search<SP, 0><<<dim3(n_blocks), dim3(PERSIST_WAVES * 64), dyn_bytes, st>>>(d_args, sl.n_calls, sl.log_key, dyn_stride);
+        k_pool_search<SP, 0><<<dim3(n_blocks), dim3(waves * 64), dyn_bytes, st>>>(d_args, sl.n_calls, sl.log_key, dyn_stride);
     }
     k_argmin_log1<SP><<<dim3(1), dim3(64), SP::dyn_bytes(a), st>>>(a, sl.n_calls, sl.log_key, sl.ctl);
 }
-void dense_launch_pool_search(const Arenas &a, const PersistArgs *d_args, const StepLaunch &sl, int n_blocks, uint32_t dyn_stride,
+void dense_launch_pool_search(const Arenas &a, const PersistArgs *d_args, const StepLaunch &sl, int n_blocks, int waves, uint32_t dyn_stride,
                               size_t dyn_bytes, void *stream) {
-    DISPATCH_DKW(a, l_pool_search, a, d_args, sl, n_blocks, dyn_stride, dyn_bytes, (hipStream_t)stream);
+    DISPATCH_DKW(a, l_pool_search, a, d_args, sl, n_blocks, waves, dyn_stride, dyn_bytes, (hipStream_t)stream);
 }
 template <class SP>
-static void q_pool_search_resident(int *out, size_t dyn_bytes) {
+static void q_pool_search_resident(int *out, int waves, size_t dyn_bytes) {
     int nb = 0;
     if (hipFuncSetAttribute((const void *)k_pool_search<SP, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn_bytes) != hipSuccess ||
-        hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, (const void *)k_pool_search<SP, 0>, PERSIST_WAVES * 64, dyn_bytes) != hipSuccess) {
+        hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, (const void *)k_pool_search<SP, 0>, waves * 64, dyn_bytes) != hipSuccess) {
         (void)hipGetLastError();
         nb = 0;
     }
     *out = nb;
 }
-int dense_pool_search_resident(const Arenas &a, size_t dyn_bytes) { // workgroups of k_pool_search one CU holds
+int dense_pool_search_resident(const Arenas &a, int waves, size_t dyn_bytes) { // workgroups of k_pool_search one CU holds
     int nb = 0;
-    DISPATCH_DKW(a, q_pool_search_resident, &nb, dyn_bytes);
+    DISPATCH_DKW(a, q_pool_search_resident, &nb, waves, dyn_bytes);
     return nb;
 }
-void launch_ext_take(const PoolArgs &pool, uint32_t *rows, uint32_t *home, uint32_t *n, uint32_t cap, void *stream) {
-    k_ext_take<<<dim3(1), dim3(POOL_XCDS * 64), 0, (hipStream_t)stream>>>(pool, rows, home, n, cap);
+void launch_ext_take(const PoolArgs &pool, uint32_t *rows, uint32_t *home, uint32_t *n, void *stream) {
+    k_ext_take<<<dim3(1), dim3(POOL_XCDS * 64), 0, (hipStream_t)stream>>>(pool, rows, home, n);
 }
 void launch_ext_hash_rows(const PersistArgs *d_args, const uint32_t *rows, const uint32_t *n, uint32_t cap, float *h_theta, void *stream) {
     k_ext_hash_rows<<<dim3(cap), dim3(256), 0, (hipStream_t)stream>>>(d_args, rows, n, h_theta);

@@ -160,13 +160,16 @@ struct azd_engine {
     uint32_t *d_call_ctr = nullptr; // [MAX_SUBS] calls a sub-population has logged in the current run
     // pool step with the evaluator outside the kernel (dense-graph space): the searchers run on `stream`, the host replays a graph of
     // [collect the posted rows, the model's GEMMs over them, hand the agents back] on ext_stream until the searchers are through
-    hipStream_t ext_stream = nullptr;
-    hipGraphExec_t ext_graph = nullptr;
+    static constexpr int EXT_STREAMS = 2;    // evaluator streams: one collects and runs its first layer while the other is in its later ones
+    static constexpr int EXT_IN_FLIGHT = 4;  // ring size per stream; replays queued at a time per stream: ext_depth
+    hipStream_t ext_stream[EXT_STREAMS] = {};
+    hipGraphExec_t ext_graph[EXT_STREAMS] = {};
     uint64_t ext_graph_layout = 0;
+    int ext_graph_n = 0;
     bool ext_unsupported = false;     // the evaluator cannot serve gathered rows from device-side lists (asked once)
-    uint32_t *d_ext_rows = nullptr, *d_ext_home = nullptr, *d_ext_n = nullptr;
-    static constexpr int EXT_IN_FLIGHT = 2;
-    hipEvent_t ext_done = nullptr, ext_fork = nullptr, ext_ring[EXT_IN_FLIGHT] = {};
+    uint32_t *d_ext_rows = nullptr, *d_ext_home = nullptr, *d_ext_n = nullptr; // [EXT_STREAMS][B], [EXT_STREAMS][B], [EXT_STREAMS]
+    int ext_depth = 2;
+    hipEvent_t ext_done = nullptr, ext_fork = nullptr, ext_ring[EXT_STREAMS][EXT_IN_FLIGHT] = {};
     unsigned long long ext_iterations = 0; // evaluator graph replays of the last dense pool launch (diagnostics)
     // dense-graph space: host-visible key width (action-id sets) and the packed roots as the device wants them
     int kw_host = 0;
@@ -797,9 +800,9 @@ int azd_engine_create(azd_engine **out, const azd_engine_config *cfg, azd_evalua
         TRY(e->alloc(&e->d_resume, B));
         TRY(e->alloc(&e->d_call_ctr, (size_t)azd_engine::MAX_SUBS));
         if (dense) {
-            TRY(e->alloc(&e->d_ext_rows, B));
-            TRY(e->alloc(&e->d_ext_home, B));
-            TRY(e->alloc(&e->d_ext_n, 1));
+            TRY(e->alloc(&e->d_ext_rows, B * azd_engine::EXT_STREAMS));
+            TRY(e->alloc(&e->d_ext_home, B * azd_engine::EXT_STREAMS));
+            TRY(e->alloc(&e->d_ext_n, (size_t)azd_engine::EXT_STREAMS));
         }
     }
     e->log_calls = 1024;
@@ -875,12 +878,14 @@ int azd_engine_destroy(azd_engine *e) {
         if (e->sub_stream[i]) (void)hipStreamDestroy(e->sub_stream[i]);
     }
     if (e->sub_fork) (void)hipEventDestroy(e->sub_fork);
-    if (e->ext_graph) (void)hipGraphExecDestroy(e->ext_graph);
     if (e->ext_done) (void)hipEventDestroy(e->ext_done);
     if (e->ext_fork) (void)hipEventDestroy(e->ext_fork);
-    for (int i = 0; i < azd_engine::EXT_IN_FLIGHT; ++i)
-        if (e->ext_ring[i]) (void)hipEventDestroy(e->ext_ring[i]);
-    if (e->ext_stream) (void)hipStreamDestroy(e->ext_stream);
+    for (int x = 0; x < azd_engine::EXT_STREAMS; ++x) {
+        if (e->ext_graph[x]) (void)hipGraphExecDestroy(e->ext_graph[x]);
+        for (int i = 0; i < azd_engine::EXT_IN_FLIGHT; ++i)
+            if (e->ext_ring[x][i]) (void)hipEventDestroy(e->ext_ring[x][i]);
+        if (e->ext_stream[x]) (void)hipStreamDestroy(e->ext_stream[x]);
+    }
     for (auto &it : e->ev_inflight) {
         (void)hipEventDestroy(it.second.first);
         (void)hipEventDestroy(it.second.second);
@@ -1024,10 +1029,13 @@ static int dense_pool_run(azd_engine *e, const azd::TolTable &t, int n_calls, bo
     const char *why = "";
     uint32_t dyn_stride = 0;
     size_t dyn_bytes = 0;
+    int waves = 16; // wavefronts per searcher workgroup
+    if (const char *env = getenv("AZD_DENSE_POOL_WAVES")) waves = atoi(env);
+    waves = waves < 1 ? 1 : waves > 16 ? 16 : waves;
     azd::FusedEval fe;
     const bool hashed = e->ev->fused_desc(&fe) && fe.kind == 4; // the test harness' fixed prediction stream, served like a model's rows
     if (!e->pool_step || !e->persist_enabled || e->pool_failed || e->ext_unsupported || a.KW > 4 || (!a.state_vecs16 && !hashed) ||
-        n_calls < 1 || !azd::dense_pool_plan(a, &dyn_stride, &dyn_bytes, &why)) {
+        n_calls < 1 || !azd::dense_pool_plan(a, waves, &dyn_stride, &dyn_bytes, &why)) {
         e->step_reason = !e->pool_step || !e->persist_enabled ? "dense-graph space: the pool step is not configured for this engine"
                          : e->pool_failed                      ? "an earlier pool launch of this engine aborted: launch-per-phase form"
                          : a.KW > 4                            ? "dense-graph space: the pool step's searchers hold up to 256 slots per root (register budget of a 16-wave workgroup)"
@@ -1036,21 +1044,30 @@ static int dense_pool_run(azd_engine *e, const azd::TolTable &t, int n_calls, bo
                              : why;
         return AZD_OK;
     }
-    const int per_cu = azd::dense_pool_search_resident(a, dyn_bytes);
-    // searcher workgroups: no more waves than twice the agents, and no more than half the chip -- the GEMM launches need the rest
-    int n_search = (a.B + 7) / 8;
-    if (n_search > e->n_cus / 2) n_search = e->n_cus / 2;
+    const int per_cu = azd::dense_pool_search_resident(a, waves, dyn_bytes);
+    // searcher workgroups: no more waves than twice the agents, and no more than half the chip's wave slots -- the GEMM launches
+    // need the rest
+    int n_search = (2 * a.B + waves - 1) / waves;
+    if (n_search > e->n_cus * 8 / waves) n_search = e->n_cus * 8 / waves;
     if (const char *env = getenv("AZD_DENSE_POOL_SEARCH_WGS")) n_search = atoi(env) > 0 ? atoi(env) : n_search;
-    if (per_cu < 1 || n_search > e->n_cus * 7 / 8) n_search = per_cu < 1 ? 0 : e->n_cus * 7 / 8;
+    if (per_cu < 1 || n_search > e->n_cus * per_cu * 7 / 8) n_search = per_cu < 1 ? 0 : e->n_cus * per_cu * 7 / 8;
     if (n_search < 1) {
         e->step_reason = "dense-graph space: the device holds no searcher workgroup of the pool step";
         return AZD_OK;
     }
-    if (!e->ext_stream) AZD_HIP(hipStreamCreateWithFlags(&e->ext_stream, hipStreamNonBlocking));
+    // (one stream by default: with two, each batch is half as large and takes as long -- the GEMMs' k loops are latency-bound at these
+    // batch sizes and the streams share the same CUs -- so an agent's cycle, which sets the rate, gets no shorter: 18.8 M expansions/s
+    // with one stream against 17.8 with two at config E)
+    int n_ext = 1;
+    if (const char *env = getenv("AZD_DENSE_POOL_STREAMS")) n_ext = atoi(env);
+    n_ext = n_ext < 1 ? 1 : n_ext > azd_engine::EXT_STREAMS ? azd_engine::EXT_STREAMS : n_ext;
     if (!e->ext_done) AZD_HIP(hipEventCreateWithFlags(&e->ext_done, hipEventDisableTiming));
     if (!e->ext_fork) AZD_HIP(hipEventCreateWithFlags(&e->ext_fork, hipEventDisableTiming));
-    for (int i = 0; i < azd_engine::EXT_IN_FLIGHT; ++i)
-        if (!e->ext_ring[i]) AZD_HIP(hipEventCreateWithFlags(&e->ext_ring[i], hipEventDisableTiming));
+    for (int x = 0; x < n_ext; ++x) {
+        if (!e->ext_stream[x]) AZD_HIP(hipStreamCreateWithFlags(&e->ext_stream[x], hipStreamNonBlocking));
+        for (int i = 0; i < azd_engine::EXT_IN_FLIGHT; ++i)
+            if (!e->ext_ring[x][i]) AZD_HIP(hipEventCreateWithFlags(&e->ext_ring[x][i], hipEventDisableTiming));
+    }
     azd::PoolArgs pool = e->pool;
     pool.n_eval = 0;
     pool.ready_lanes = 0;
@@ -1062,30 +1079,44 @@ static int dense_pool_run(azd_engine *e, const azd::TolTable &t, int n_calls, bo
     pool.eval_stride = pool.eval_out_off = 0;
     pool.eval_rows = 0;
     pool.debug_abort_call = 0;
-    // the evaluator's graph: collect, the layers over the collected rows, hand back
-    if (!e->ext_graph || e->ext_graph_layout != e->ev->layout_version + (hashed ? 1ull << 63 : 0ull)) {
-        if (e->ext_graph) (void)hipGraphExecDestroy(e->ext_graph);
-        e->ext_graph = nullptr;
-        hipGraph_t g = nullptr;
-        AZD_HIP(hipStreamBeginCapture(e->ext_stream, hipStreamCaptureModeThreadLocal));
-        azd::launch_ext_take(pool, e->d_ext_rows, e->d_ext_home, e->d_ext_n, (uint32_t)a.B, e->ext_stream);
-        int st_g = AZD_OK;
-        if (hashed) azd::launch_ext_hash_rows(e->d_pargs, e->d_ext_rows, e->d_ext_n, (uint32_t)a.B, a.h_theta, e->ext_stream);
-        else st_g = e->ev->write_predictions_gathered(e->d_ext_rows, e->d_ext_n, a.B, a.state_vecs16, a.S16, a.h_theta, e->ext_stream);
-        azd::launch_ext_deliver(pool, a, e->d_ext_rows, e->d_ext_home, e->d_ext_n, (uint32_t)a.B, e->ext_stream);
-        const hipError_t he = hipStreamEndCapture(e->ext_stream, &g);
-        if (st_g) {
-            if (g) (void)hipGraphDestroy(g);
-            if (st_g != AZD_ERR_UNSUPPORTED) return st_g;
-            e->ext_unsupported = true;
-            e->step_reason = "dense-graph space: the pool step needs an evaluator that serves gathered bf16 rows (ActionModel with bf16 storage)";
-            return AZD_OK;
+    // the evaluator's graphs, one per stream: collect, the layers over the collected rows, hand back.  Every stream may find the
+    // whole population posted, so each has row lists and activation rows of its own.
+    if (!hashed) {
+        const int st_r = e->ev->ensure_rows(n_ext * a.B);
+        if (st_r) return st_r;
+    }
+    const uint64_t layout = e->ev->layout_version + (hashed ? 1ull << 63 : 0ull);
+    if (e->ext_graph_n != n_ext || e->ext_graph_layout != layout) {
+        for (int x = 0; x < azd_engine::EXT_STREAMS; ++x)
+            if (e->ext_graph[x]) {
+                (void)hipGraphExecDestroy(e->ext_graph[x]);
+                e->ext_graph[x] = nullptr;
+            }
+        e->ext_graph_n = 0;
+        for (int x = 0; x < n_ext; ++x) {
+            uint32_t *rows = e->d_ext_rows + (size_t)x * a.B, *home = e->d_ext_home + (size_t)x * a.B, *cnt = e->d_ext_n + x;
+            hipGraph_t g = nullptr;
+            AZD_HIP(hipStreamBeginCapture(e->ext_stream[x], hipStreamCaptureModeThreadLocal));
+            azd::launch_ext_take(pool, rows, home, cnt, e->ext_stream[x]);
+            int st_g = AZD_OK;
+            if (hashed) azd::launch_ext_hash_rows(e->d_pargs, rows, cnt, (uint32_t)a.B, a.h_theta, e->ext_stream[x]);
+            else st_g = e->ev->write_predictions_gathered(rows, cnt, a.B, a.state_vecs16, a.S16, a.h_theta, e->ext_stream[x], x * a.B);
+            azd::launch_ext_deliver(pool, a, rows, home, cnt, (uint32_t)a.B, e->ext_stream[x]);
+            const hipError_t he = hipStreamEndCapture(e->ext_stream[x], &g);
+            if (st_g) {
+                if (g) (void)hipGraphDestroy(g);
+                if (st_g != AZD_ERR_UNSUPPORTED) return st_g;
+                e->ext_unsupported = true;
+                e->step_reason = "dense-graph space: the pool step needs an evaluator that serves gathered bf16 rows (ActionModel with bf16 storage)";
+                return AZD_OK;
+            }
+            if (he != hipSuccess) return azd::hip_fail(he, "hipStreamEndCapture");
+            const hipError_t hi = hipGraphInstantiate(&e->ext_graph[x], g, nullptr, nullptr, 0);
+            (void)hipGraphDestroy(g);
+            if (hi != hipSuccess) return azd::hip_fail(hi, "hipGraphInstantiate");
         }
-        if (he != hipSuccess) return azd::hip_fail(he, "hipStreamEndCapture");
-        const hipError_t hi = hipGraphInstantiate(&e->ext_graph, g, nullptr, nullptr, 0);
-        (void)hipGraphDestroy(g);
-        if (hi != hipSuccess) return azd::hip_fail(hi, "hipGraphInstantiate");
-        e->ext_graph_layout = e->ev->layout_version + (hashed ? 1ull << 63 : 0ull);
+        e->ext_graph_n = n_ext;
+        e->ext_graph_layout = layout;
     }
     if (!hashed) {
         memset(&fe, 0, sizeof(fe));
@@ -1095,7 +1126,7 @@ static int dense_pool_run(azd_engine *e, const azd::TolTable &t, int n_calls, bo
     e->step_reason.clear();
     e->pool_eval_wgs = 0;
     e->pool_search_wgs = n_search;
-    e->pool_search_waves = n_search * 16;
+    e->pool_search_waves = n_search * waves;
     e->ext_iterations = 0;
     int left = n_calls;
     while (left > 0) {
@@ -1122,9 +1153,9 @@ static int dense_pool_run(azd_engine *e, const azd::TolTable &t, int n_calls, bo
             AZD_HIP(hipMemsetAsync(e->d_log_key, 0xFF, (size_t)e->log_calls * sizeof(unsigned long long), e->stream));
             e->log_clean = true;
         }
-        AZD_HIP(hipMemsetAsync(e->d_ext_n, 0, sizeof(uint32_t), e->stream));
+        AZD_HIP(hipMemsetAsync(e->d_ext_n, 0, sizeof(uint32_t) * azd_engine::EXT_STREAMS, e->stream));
         AZD_HIP(hipEventRecord(e->ext_fork, e->stream));
-        AZD_HIP(hipStreamWaitEvent(e->ext_stream, e->ext_fork, 0)); // the evaluator's first collect sees the cleared queues
+        for (int x = 0; x < n_ext; ++x) AZD_HIP(hipStreamWaitEvent(e->ext_stream[x], e->ext_fork, 0)); // the first collect sees the cleared queues
         azd::StepLaunch sl;
         sl.n_calls = k;
         sl.log_key = e->d_log_key;
@@ -1133,26 +1164,32 @@ static int dense_pool_run(azd_engine *e, const azd::TolTable &t, int n_calls, bo
         sl.hashed = hashed ? 1 : 0;
         sl.window = 0;
         e->time_begin(0);
-        azd::dense_launch_pool_search(a, e->d_pargs, sl, n_search, dyn_stride, dyn_bytes, e->stream);
+        azd::dense_launch_pool_search(a, e->d_pargs, sl, n_search, waves, dyn_stride, dyn_bytes, e->stream);
         e->time_end();
         AZD_HIP(hipGetLastError());
         AZD_HIP(hipEventRecord(e->ext_done, e->stream));
         e->pool_clean = false;
-        // the evaluator: replayed until the searchers (and the argmin replay behind them) are through, EXT_IN_FLIGHT replays queued
-        // at a time -- a replay that finds nothing posted costs a few microseconds
+        // the evaluator: replayed, stream after stream, until the searchers (and the argmin replay behind them) are through; ext_depth
+        // replays queued per stream at a time -- a replay that finds nothing posted costs a few microseconds
         unsigned long long it = 0;
+        int depth = e->ext_depth;
+        if (const char *env = getenv("AZD_DENSE_POOL_DEPTH")) depth = atoi(env);
+        depth = depth < 1 ? 1 : depth > azd_engine::EXT_IN_FLIGHT ? azd_engine::EXT_IN_FLIGHT : depth;
         for (;;) {
             const hipError_t q = hipEventQuery(e->ext_done);
             if (q == hipSuccess) break;
             if (q != hipErrorNotReady) return azd::hip_fail(q, "hipEventQuery");
-            hipEvent_t slot = e->ext_ring[it % azd_engine::EXT_IN_FLIGHT];
-            if (it >= (unsigned long long)azd_engine::EXT_IN_FLIGHT) AZD_HIP(hipEventSynchronize(slot));
-            AZD_HIP(hipGraphLaunch(e->ext_graph, e->ext_stream));
-            AZD_HIP(hipEventRecord(slot, e->ext_stream));
+            const int x = (int)(it % (unsigned long long)n_ext);
+            const unsigned long long round = it / (unsigned long long)n_ext;
+            hipEvent_t slot = e->ext_ring[x][round % (unsigned long long)depth];
+            if (round >= (unsigned long long)depth) AZD_HIP(hipEventSynchronize(slot));
+            AZD_HIP(hipGraphLaunch(e->ext_graph[x], e->ext_stream[x]));
+            AZD_HIP(hipEventRecord(slot, e->ext_stream[x]));
             it += 1;
         }
-        AZD_HIP(hipStreamSynchronize(e->ext_stream));
+        for (int x = 0; x < n_ext; ++x) AZD_HIP(hipStreamSynchronize(e->ext_stream[x]));
         e->ext_iterations += it;
+        if (getenv("AZD_DENSE_POOL_DEBUG")) fprintf(stderr, "dense pool: %d calls, %d searcher workgroups, %llu evaluator replays\n", k, n_search, it);
         left -= k;
         e->ev->calls += (uint64_t)k;
         st = fetch_status(e);

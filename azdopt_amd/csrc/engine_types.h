@@ -332,11 +332,11 @@ void dense_launch_argmin_log(const Arenas &a, int n_calls, unsigned long long *l
 void dense_launch_observe(const Arenas &a, uint32_t n_obs_tol, void *stream);
 // pool step of the dense-graph space: searcher workgroups only (k_pool_search); the evaluator is a stream of batched GEMM launches
 // over the rows the searchers have posted, collected by k_ext_take and handed back by k_ext_deliver (pool_step.inc)
-bool dense_pool_plan(const Arenas &a, uint32_t *dyn_stride, size_t *dyn_bytes, const char **why);
-void dense_launch_pool_search(const Arenas &a, const PersistArgs *d_args, const StepLaunch &sl, int n_blocks, uint32_t dyn_stride,
+bool dense_pool_plan(const Arenas &a, int waves, uint32_t *dyn_stride, size_t *dyn_bytes, const char **why);
+void dense_launch_pool_search(const Arenas &a, const PersistArgs *d_args, const StepLaunch &sl, int n_blocks, int waves, uint32_t dyn_stride,
                               size_t dyn_bytes, void *stream);
-int dense_pool_search_resident(const Arenas &a, size_t dyn_bytes);
-void launch_ext_take(const PoolArgs &pool, uint32_t *rows, uint32_t *home, uint32_t *n, uint32_t cap, void *stream);
+int dense_pool_search_resident(const Arenas &a, int waves, size_t dyn_bytes);
+void launch_ext_take(const PoolArgs &pool, uint32_t *rows, uint32_t *home, uint32_t *n, void *stream);
 void launch_ext_hash_rows(const PersistArgs *d_args, const uint32_t *rows, const uint32_t *n, uint32_t cap, float *h_theta, void *stream);
 void launch_ext_deliver(const PoolArgs &pool, const Arenas &a, const uint32_t *rows, const uint32_t *home, const uint32_t *n, uint32_t cap,
                         void *stream);

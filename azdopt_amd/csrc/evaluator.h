@@ -52,11 +52,14 @@ struct azd_evaluator {
                                        d_p + (size_t)row0 * action_dim, st);
     }
     virtual bool rows_concurrent() { return false; }
+    virtual int ensure_rows(int /*rows*/) { return AZD_OK; } // the evaluator's own buffers hold this many rows from here on (may bump layout_version)
     // The pool step's evaluator outside the kernel (engine.hip, dense-graph space): predictions for the *d_count (<= max_rows) rows
     // whose indices stand in d_rows -- inputs d_s16[row], outputs d_p[row] -- with everything the launches need in device memory,
     // so that the sequence can be captured once and replayed.  AZD_ERR_UNSUPPORTED: this evaluator cannot (the engine asks once).
+    // act_row0: first row of the evaluator's own buffers this call may use (calls on disjoint ranges [act_row0, act_row0 + max_rows) may
+    // run at the same time on different streams).
     virtual int write_predictions_gathered(const uint32_t * /*d_rows*/, const uint32_t * /*d_count*/, int /*max_rows*/, const uint16_t * /*d_s16*/,
-                                           int /*pitch16*/, float * /*d_p*/, hipStream_t /*st*/) {
+                                           int /*pitch16*/, float * /*d_p*/, hipStream_t /*st*/, int /*act_row0*/ = 0) {
         return AZD_ERR_UNSUPPORTED;
     }
     // description for the persistent step (evaluator inside the kernel); false = not fusable

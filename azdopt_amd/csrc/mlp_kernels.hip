@@ -604,20 +604,23 @@ struct MlpEvaluator : azd_evaluator {
         return forward16(count, d_s + (size_t)row0 * state_dim, x16, d_p + (size_t)row0 * action_dim, st, row0);
     }
     bool rows_concurrent() override { return bf16 && d_w16p && !getenv("AZD_GEMM_OLD"); }
-    int write_predictions_gathered(const uint32_t *d_rows, const uint32_t *d_count, int max_rows, const uint16_t *d_s16, int pitch16, float *d_p,
-                                   hipStream_t st) override {
-        if (!rows_concurrent() || !d_s16 || pitch16 != kp[0]) return AZD_ERR_UNSUPPORTED;
+    int ensure_rows(int rows) override {
         AZD_HIP(hipSetDevice(device));
-        int s = ensure_batch(max_rows);
-        if (s) return s;
+        return ensure_batch(rows);
+    }
+    int write_predictions_gathered(const uint32_t *d_rows, const uint32_t *d_count, int max_rows, const uint16_t *d_s16, int pitch16, float *d_p,
+                                   hipStream_t st, int act_row0) override {
+        if (!rows_concurrent() || !d_s16 || pitch16 != kp[0]) return AZD_ERR_UNSUPPORTED;
+        if (act_row0 + max_rows > cap_batch) return AZD_ERR_CAPACITY; // (the engine sizes the evaluator first: ensure_rows)
+        AZD_HIP(hipSetDevice(device));
         const uint16_t *x16 = d_s16;
         for (int l = 0; l < L; ++l) {
             const bool last = l == L - 1;
-            void *y = last ? (void *)d_p : (void *)d_act16[(size_t)l + 1];
+            void *y = last ? (void *)d_p : (void *)(d_act16[(size_t)l + 1] + (size_t)act_row0 * kp[(size_t)l + 1]);
             launch_gemm16_ext(st, x16, kp[(size_t)l], d_w16p + wp_off[(size_t)l], kp[(size_t)l], y, last ? dims[(size_t)L] : kp[(size_t)l + 1], max_rows,
                               dims[(size_t)l + 1], kp[(size_t)l], last ? final_act : AZD_ACT_RELU, last ? 0 : 1, d_params + b_off[(size_t)l], n_cus, d_count,
                               l == 0 ? d_rows : nullptr, last ? d_rows : nullptr);
-            if (!last) x16 = d_act16[(size_t)l + 1];
+            if (!last) x16 = d_act16[(size_t)l + 1] + (size_t)act_row0 * kp[(size_t)l + 1];
         }
         AZD_HIP(hipGetLastError());
         return AZD_OK;
@@ -872,10 +875,11 @@ extern "C" int azd_debug_gemm_bf16(int device, int M, int N, int Kp, const void 
     hipEvent_t e0, e1;
     AZD_HIP(hipEventCreate(&e0));
     AZD_HIP(hipEventCreate(&e1));
-    azd::launch_gemm16(st, (const uint16_t *)d_a, Kp, (const uint16_t *)d_w, Kp, d_y, ldy, M, N, Kp, act, out_bf16, d_bias, prop.multiProcessorCount);
+    const int force_bn = getenv("AZD_GEMM16_BN") ? atoi(getenv("AZD_GEMM16_BN")) : 0; // (this entry only: tile experiments)
+    azd::launch_gemm16(st, (const uint16_t *)d_a, Kp, (const uint16_t *)d_w, Kp, d_y, ldy, M, N, Kp, act, out_bf16, d_bias, prop.multiProcessorCount, force_bn);
     AZD_HIP(hipEventRecord(e0, st));
     for (int r = 0; r < reps; ++r)
-        azd::launch_gemm16(st, (const uint16_t *)d_a, Kp, (const uint16_t *)d_w, Kp, d_y, ldy, M, N, Kp, act, out_bf16, d_bias, prop.multiProcessorCount);
+        azd::launch_gemm16(st, (const uint16_t *)d_a, Kp, (const uint16_t *)d_w, Kp, d_y, ldy, M, N, Kp, act, out_bf16, d_bias, prop.multiProcessorCount, force_bn);
     AZD_HIP(hipEventRecord(e1, st));
     AZD_HIP(hipStreamSynchronize(st));
     AZD_HIP(hipGetLastError());
