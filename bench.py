@@ -376,7 +376,7 @@ def main():
         # Per call with a new node: two round trips per selection level (the pool step takes the first level's choice from
         # add_actions' registers), two per table probe, two per cascade (the path's records in one gather, then the arcs of a
         # node with several parents), six for the hand-overs (state in, row / request out, queue words).
-        sel = d["SELECT_CALLS"] - (d["EXPANSIONS"] if form == "pool" else 0)
+        sel = d["SELECT_CALLS"] - (d["EXPANSIONS"] if (form == "pool" and wl["kind"] != "dense") else 0)
         events = d["TERMINALS"] + d["TRANSPOSITIONS"]
         chain = (2 * sel + 2 * (d["EXPANSIONS"] + events) + 2 * events) / max(1, d["EXPANSIONS"]) + 6
         waves = opt.pool_split()[1] * 16 if form == "pool" else min(B, 4096)

@@ -14,6 +14,7 @@ if has bench; then
   for cfg in A C D; do timeout -k 10 300 python bench.py --no-cpu-baseline --config $cfg > $O/bench_$cfg.log 2>&1; done
   timeout -k 10 300 python bench.py --no-cpu-baseline --agents 8192 > $O/bench_B8192.log 2>&1
   timeout -k 10 400 python bench.py --config E --steps 400 --warmup 50 > $O/bench_E.log 2>&1
+  AZD_DENSE_NO_POOL=1 timeout -k 10 400 python bench.py --config E --steps 400 --warmup 50 --no-cpu-baseline > $O/bench_E_per_call.log 2>&1
   timeout -k 10 400 python bench.py --config E --steps 200 --warmup 50 --agents 1024 --max-slots 612 --prediction-capacity 524288 --no-cpu-baseline > $O/bench_E612.log 2>&1
   echo benches done
 fi
@@ -44,12 +45,15 @@ if has split; then
   echo split done
 fi
 if has curve; then
-  { timeout -k 10 300 python tools/launch_curve.py B 1 5 20 800; AZD_LIB=$PWD/azdopt_amd/libazdopt_amd_r02.so timeout -k 10 300 python tools/launch_curve.py B 1 5 20 800
-    timeout -k 10 300 python tools/launch_curve.py A 1 5 20 800; AZD_LIB=$PWD/azdopt_amd/libazdopt_amd_r02.so timeout -k 10 300 python tools/launch_curve.py A 1 5 20 800; } > $O/curve.txt 2>&1
+  { timeout -k 10 300 python tools/launch_curve.py B 1 5 20 800 w1 w5; AZD_LIB=$PWD/azdopt_amd/libazdopt_amd_r02.so timeout -k 10 300 python tools/launch_curve.py B 1 5 20 800
+    timeout -k 10 300 python tools/launch_curve.py A 1 5 20 800 w1; AZD_LIB=$PWD/azdopt_amd/libazdopt_amd_r02.so timeout -k 10 300 python tools/launch_curve.py A 1 5 20 800; } > $O/curve.txt 2>&1
   echo curve done
 fi
 if has examples; then
-  { for stride in 1 800; do /usr/bin/time -f "stride $stride: %e s wall" examples/c21_tree 3 800 512 $stride 0 2>&1 | tail -3; done; } > $O/examples.txt 2>&1
+  g++ -O2 -std=c++17 -Iinclude examples/c21_tree.cpp -o $O/c21_tree -Lazdopt_amd -lazdopt_amd -Wl,-rpath,$PWD/azdopt_amd
+  TIMEFORMAT="%R s wall"
+  { for stride in 1 800; do echo "512 agents, 512-1024-512, stride $stride:"; time $O/c21_tree 3 800 512 $stride 0 2>&1 | tail -2; done
+    for stride in 1 800; do echo "4096 agents, 3 x 256, stride $stride:"; time $O/c21_tree 3 800 4096 $stride 0 256 256 256 2>&1 | tail -2; done; } > $O/examples.txt 2>&1
   echo examples done
 fi
 echo all done

@@ -82,9 +82,9 @@ for src, dst in (("prof/**/*kernel_stats.csv", "_pool_kernel_stats.csv"), ("prof
     if f:
         shutil.copy(f, os.path.join(P, R + dst))
         for row in csv.DictReader(open(f)):
-            if any(k in row["Name"] for k in ("k_pool", "k_gemm16", "k_rollout", "k_gemm_bf16")):
+            if any(k in row["Name"] for k in ("k_pool", "k_gemm16", "k_rollout", "k_gemm_bf16", "k_ext_")):
                 print("rocprofv3 %-28s %-60s launches %5s avg ms %.4f" % (dst, row["Name"][:60], row["Calls"], float(row["AverageNs"]) / 1e6))
-names = ("default", "driver20", "B_async", "A", "C", "D", "B8192", "E", "E612")
+names = ("default", "driver20", "B_async", "A", "C", "D", "B8192", "E", "E_per_call", "E612")
 with open(os.path.join(P, R + "_bench_lines.txt"), "w") as f:
     for name in names:
         line = bench_line(name)
@@ -94,8 +94,8 @@ with open(os.path.join(P, R + "_bench_lines.txt"), "w") as f:
         d = json.loads(line)
         print(f"{name:12s} {d['value'] / 1e6:6.2f} M  {d['ms_per_step'] * 1e3:7.1f} us/call  {d['step_form']:14s} frac {d['roofline']['frac']:.4f}  "
               f"launch {d['roofline']['avg_launch_ms']:.2f} ms  split {d.get('pool_split')}")
-    for extra, title in (("curve.txt", "calls per launch (tools/launch_curve.py; the second block of each config: round 2's library, libazdopt_amd_r02.so)"),
-                         ("examples.txt", "examples/c21_tree (the reference's driver loop over the C ABI) at stride 1 and 800: 3 epochs x 800 episodes, 512 agents")):
+    for extra, title in (("curve.txt", "calls per launch, and calls per request inside a run-ahead window (tools/launch_curve.py; the second block of each config: round 2's library, libazdopt_amd_r02.so)"),
+                         ("examples.txt", "examples/c21_tree (the reference's driver loop over the C ABI) at stride 1 (answered from a run-ahead window) and 800: 3 epochs x 800 episodes")):
         if os.path.exists(os.path.join(O, extra)):
             f.write("### %s\n%s" % (title, txt(extra)))
 for src, dst, head in (("gemm.txt", "_gemm.txt", "# tools/time_gemm16.py (the LDS-DMA bf16 GEMM in isolation, checked against torch) and tools/time_gemm.py (the evaluator's forward;\n# the last line: the round-2 kernel, AZD_GEMM_OLD=1)\n"),
