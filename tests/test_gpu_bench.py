@@ -1,0 +1,42 @@
+"""bench.py end to end on the GPU at reduced sizes: the contract line (metric, value, roofline, cpu_baseline, step form) of the
+default workload inside the driver's short window, and of BASELINE configs[4] on its CU-resident form."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def bench(*args):
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), *args], capture_output=True, text=True, timeout=600, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [x for x in r.stdout.splitlines() if x.startswith('{"metric')]
+    assert len(lines) == 1, r.stdout[-2000:]
+    return json.loads(lines[0])
+
+
+def test_bench_line_of_the_default_workload_in_the_drivers_window():
+    j = bench("--steps", "20", "--warmup", "5", "--agents", "512", "--cpu-seconds", "2")
+    assert j["metric"] == "node_expansions_per_s" and j["unit"] == "expansions/s" and j["n_gpus"] == 1 and j["steps"] == 20 and j["warmup"] == 5
+    assert j["higher_is_better"] is True and j["scaling"] == "weak" and j["vs_baseline"] is None and j["data"] == "synthetic"
+    assert j["value"] > 1e5 and abs(j["ms_per_step"] * 1e-3 * j["value"] - j["expansions"] / 20) < 1e-6 * j["expansions"]
+    assert j["step_form"] == "pool" and j["dtype"] == "f32" and "workload" in j["config"]
+    r = j["roofline"]
+    assert r["bound"] == "hbm" and r["unit"] == "GB/s" and r["peak"] == 8000.0 and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-12
+    assert r["kernel"].startswith("k_pool<") and r["avg_launch_ms"] > 0
+    c = j["cpu_baseline"]
+    assert c["kind"] == "port" and c["cores"] >= 1 and c["value"] > 0 and "sample" in c
+    assert j["epoch_boundaries_in_timed_region"] == 0 and j["replicas_identical"] is True
+
+
+def test_bench_line_of_config_e_on_the_pool_searchers():
+    j = bench("--config", "E", "--agents", "1024", "--steps", "30", "--warmup", "10", "--no-cpu-baseline")
+    assert j["step_form"] == "pool" and j["step_form_reason"] == "" and j["dtype"] == "bf16"
+    assert j["pool_split"][0] == 0 and j["pool_split"][1] >= 1  # searcher workgroups only: the evaluator is a stream of GEMM launches
+    assert "outside the kernel" in j["evaluator_form"]
+    assert j["roofline"]["kernel"] == "k_pool_search<2>" and j["value"] > 1e5
+    assert "128" in j["config"]["workload"]  # the slot cap is stated
