@@ -1085,7 +1085,10 @@ static int dense_pool_run(azd_engine *e, const azd::TolTable &t, int n_calls, bo
         const int st_r = e->ev->ensure_rows(n_ext * a.B);
         if (st_r) return st_r;
     }
-    const uint64_t layout = e->ev->layout_version + (hashed ? 1ull << 63 : 0ull);
+    int rounds = 4; // collect / layers / hand-back rounds per replay of the evaluator's graph
+    if (const char *env = getenv("AZD_DENSE_POOL_ROUNDS")) rounds = atoi(env);
+    rounds = rounds < 1 ? 1 : rounds > 16 ? 16 : rounds;
+    const uint64_t layout = e->ev->layout_version + (hashed ? 1ull << 63 : 0ull) + ((uint64_t)rounds << 56);
     if (e->ext_graph_n != n_ext || e->ext_graph_layout != layout) {
         for (int x = 0; x < azd_engine::EXT_STREAMS; ++x)
             if (e->ext_graph[x]) {
@@ -1097,11 +1100,14 @@ static int dense_pool_run(azd_engine *e, const azd::TolTable &t, int n_calls, bo
             uint32_t *rows = e->d_ext_rows + (size_t)x * a.B, *home = e->d_ext_home + (size_t)x * a.B, *cnt = e->d_ext_n + x;
             hipGraph_t g = nullptr;
             AZD_HIP(hipStreamBeginCapture(e->ext_stream[x], hipStreamCaptureModeThreadLocal));
-            azd::launch_ext_take(pool, rows, home, cnt, e->ext_stream[x]);
             int st_g = AZD_OK;
-            if (hashed) azd::launch_ext_hash_rows(e->d_pargs, rows, cnt, (uint32_t)a.B, a.h_theta, e->ext_stream[x]);
-            else st_g = e->ev->write_predictions_gathered(rows, cnt, a.B, a.state_vecs16, a.S16, a.h_theta, e->ext_stream[x], x * a.B);
-            azd::launch_ext_deliver(pool, a, rows, home, cnt, (uint32_t)a.B, e->ext_stream[x]);
+            // several rounds per graph: between two graphs on a stream the GPU idles ~18 us, between two kernels of one graph not at all
+            for (int r = 0; r < rounds && st_g == AZD_OK; ++r) {
+                azd::launch_ext_take(pool, rows, home, cnt, e->ext_stream[x]);
+                if (hashed) azd::launch_ext_hash_rows(e->d_pargs, rows, cnt, (uint32_t)a.B, a.h_theta, e->ext_stream[x]);
+                else st_g = e->ev->write_predictions_gathered(rows, cnt, a.B, a.state_vecs16, a.S16, a.h_theta, e->ext_stream[x], x * a.B);
+                azd::launch_ext_deliver(pool, a, rows, home, cnt, (uint32_t)a.B, e->ext_stream[x]);
+            }
             const hipError_t he = hipStreamEndCapture(e->ext_stream[x], &g);
             if (st_g) {
                 if (g) (void)hipGraphDestroy(g);
