@@ -123,7 +123,7 @@ class NablaOptimizer:
 
     def run_ahead(self, n_as_tol, n_calls):
         """Start the next n_calls calls of par_roll_out_episodes(n_as_tol, ...) now, in one launch; the calls that ask for them --
-        one at a time as in 04-c21-tree.rs:132-160, or in chunks -- launch nothing and are answered as the kernel completes
+        one at a time as in 04-c21-tree.rs:142-150, or in chunks -- launch nothing and are answered as the kernel completes
         them (azd_engine_run_ahead).  Returns False when this engine's step form cannot do that: the calls then run when asked for."""
         t, d = self._tol(n_as_tol)
         ok = C.c_int32()

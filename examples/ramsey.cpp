@@ -64,6 +64,9 @@ int main(int argc, char **argv) {
         if (process_argmin(opt.argmin_data())) return 0;
         for (int epoch = 1; epoch <= epochs; ++epoch) {
             std::printf("==== EPOCH: %d ====\n", epoch);
+            // the drivers ask for their episodes one call at a time (02-r44.rs:135-143): the epoch's calls are started in one launch
+            // and the loop below is answered as they complete (a no-op where the engine cannot do that)
+            if (stride < episodes) opt.run_ahead(d->tol, episodes);
             for (int done = 0; done < episodes;) {
                 const int k = stride < episodes - done ? stride : episodes - done;
                 if (opt.par_roll_out_episodes(d->tol, k) && process_argmin(opt.argmin_data())) return 0;

@@ -59,6 +59,8 @@ def main():
     for epoch in range(1, args.epochs + 1):
         print("==== EPOCH: %d ====" % epoch)
         done = 0
+        if args.stride < episodes:  # the epoch's calls in one launch, handed out call by call (NablaOptimizer.run_ahead)
+            opt.run_ahead(d["tol"], episodes)
         while done < episodes:
             k = min(args.stride, episodes - done)
             if opt.par_roll_out_episodes(d["tol"], n_calls=k):

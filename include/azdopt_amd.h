@@ -316,7 +316,7 @@ int azd_engine_par_new(azd_engine *e, const uint8_t *parents, const uint64_t *pe
 int azd_engine_par_roll_out_episodes(azd_engine *e, const uint32_t *n_as_tol, int n_tol,
                                      uint32_t n_as_tol_default, int n_calls, int *improved);
 /* Run-ahead window, for a host that asks for its episodes ONE CALL AT A TIME as the reference's drivers do
- * (04-c21-tree.rs:132-160: par_roll_out_episodes, then a look at the ArgminImprovement, `episodes` times per epoch): a
+ * (04-c21-tree.rs:142-150: par_roll_out_episodes, then a look at the ArgminImprovement, `episodes` times per epoch): a
  * launch of the CU-resident step costs ~0.6 ms whatever it holds, so 800 launches of one call run at a fifth of the speed
  * of one launch of 800.  azd_engine_run_ahead starts the next `n_calls` calls NOW, in one launch, and returns at once;
  * the azd_engine_par_roll_out_episodes calls that follow (same n_as_tol; one call or any chunk at a time) launch nothing:

@@ -342,7 +342,7 @@ public:
         return improved;
     }
     // Starts the next n_calls calls of par_roll_out_episodes(n_as_tol, ...) now, in one launch; the calls that ask for them (one at a
-    // time, as in 04-c21-tree.rs:132-160, or in chunks) are answered as the kernel completes them (azd_engine_run_ahead).  False:
+    // time, as in 04-c21-tree.rs:142-150, or in chunks) are answered as the kernel completes them (azd_engine_run_ahead).  False:
     // this engine's step cannot do that (or the model lives on the host), and the calls run when they are asked for.
     bool run_ahead(const Tolerance &n_as_tol, int n_calls) {
         if (host_) return false;
