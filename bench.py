@@ -43,9 +43,11 @@ SEED = 0
 # they keep the drivers' n_as_tol tables (01-r333.rs:128-130, 02-r44.rs:128-130) and use 800-call epochs
 # like c21 (the drivers run 6400 / 3200) so that the arenas stay under 20 GB.
 WORKLOADS = {
-    "c21": dict(kind="c21", n=19, agents=4096, hidden=(256, 256, 256), tol=([200, 50, 50], 25), caps={}, name="c21 N=19"),
+    # (prediction arena: an epoch of 800 calls makes at most 801 nodes of at most ACTION / 2 = 76 actions each; the engine's default
+    # of 32768 holds the first epochs' trees and overflows -- loudly -- once the trained model sends the searches deeper)
+    "c21": dict(kind="c21", n=19, agents=4096, hidden=(256, 256, 256), tol=([200, 50, 50], 25), caps=dict(prediction_capacity=65536), name="c21 N=19"),
     # the reference's own run (04-c21-tree.rs:33-54): B = 512, MLP 304-512-1024-512-152
-    "c21ref": dict(kind="c21", n=19, agents=512, hidden=(512, 1024, 512), tol=([200, 50, 50], 25), caps={}, name="c21 N=19"),
+    "c21ref": dict(kind="c21", n=19, agents=512, hidden=(512, 1024, 512), tol=([200, 50, 50], 25), caps=dict(prediction_capacity=65536), name="c21 N=19"),
     "r333": dict(kind="ramsey", n=16, sizes=[3, 3, 3], agents=8192, hidden=(256, 256, 256),
                  tol=([200, 200, 200, 100, 100, 100, 50, 50, 50, 25, 25, 25], 10),
                  caps=dict(prediction_capacity=98304), name="Ramsey R(3,3,3) N=16"),

@@ -49,7 +49,10 @@ int main(int argc, char **argv) {
         azdopt::ActionModel model(batch, space.STATE_DIM(), space.ACTION_DIM(), hidden, adam, seed);
         const int kmin = 5, kmax = space.ACTION_DIM() / 2;     // :85
         const azdopt::Roots roots = space.generate_roots(seed, batch, kmin, kmax);
-        auto opt = azdopt::NablaOptimizer<azdopt::ROTModifyParentsOnce>::par_new(space, roots, model, batch);
+        // arenas for one epoch's tree at its largest: a node per episode, at most kmax predictions per node (the reference's Vecs grow)
+        auto cap = [](int a, int b) { return a > b ? a : b; };
+        auto opt = azdopt::NablaOptimizer<azdopt::ROTModifyParentsOnce>::par_new(space, roots, model, batch, 0, 0, 0, cap(4096, episodes + 64),
+                                                                                 cap(8192, 3 * episodes + 64), cap(32768, (episodes + 1) * kmax + 128));
         if (process_argmin(opt.argmin_data())) return 0;
         const azdopt::Tolerance n_as_tol = {{200, 50, 50}, 25}; // :134-136
         const uint32_t n_obs_tol = 200;
