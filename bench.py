@@ -434,6 +434,19 @@ def main():
                                  "dependent_round_trips_per_call": chain, "miss_latency_ns": 375,
                                  "note": "peak = searching waves / (dependent gathers per call x idle HBM-miss latency)"},
         }
+        # the evaluator's side against the matrix-core peak of the CUs it holds (MI355X_MICROARCH.md: 157.3 TFLOP/s fp32 on the
+        # matrix cores, 2.5 PFLOP/s bf16 dense, over 256 CUs): evaluator workgroups of the pool step, or -- dense-graph space -- the
+        # CUs the searchers leave to the GEMM launches
+        if mlp_dtype and form == "pool":
+            flop_per_row = 2.0 * sum(a * b for a, b in zip((space.STATE_DIM,) + HIDDEN, HIDDEN + (space.ACTION_DIM,)))
+            split = opt.pool_split()
+            cus = (256 - split[1]) if wl["kind"] == "dense" else split[0]
+            chip_peak = 157.3 if mlp_dtype == "f32" else 2500.0
+            ach = flop_per_row * (exp_total / world) / dt_max / 1e12
+            out["evaluator_mfma"] = {"bound": "mfma", "achieved": ach, "peak": chip_peak * cus / 256.0, "unit": "TFLOP/s",
+                                     "frac": ach / (chip_peak * cus / 256.0) if cus else None, "cus": cus, "flop_per_row": flop_per_row,
+                                     "note": "rows served per second x the model's flop per row, against the dense matrix-core peak of the CUs "
+                                             "the evaluator side holds (%s storage)" % ("fp32" if mlp_dtype == "f32" else "bf16")}
         if not args.no_cpu_baseline and world == 1:  # timed beside the GPU run at N = 1 only
             out["cpu_baseline"] = cpu_baseline(min(os.cpu_count() or 1, 64), wl, HIDDEN, space.default_permitted_range(), args.cpu_seconds)
         else:
