@@ -1029,16 +1029,18 @@ static int dense_pool_run(azd_engine *e, const azd::TolTable &t, int n_calls, bo
     const char *why = "";
     uint32_t dyn_stride = 0;
     size_t dyn_bytes = 0;
-    int waves = 16; // wavefronts per searcher workgroup
+    // wavefronts per searcher workgroup: 16, or as many as the LDS holds (roots of more than 640 slots: 12 -- a wave's block and its
+    // selection scratch are 12 KB there)
+    int waves = 16;
     if (const char *env = getenv("AZD_DENSE_POOL_WAVES")) waves = atoi(env);
     waves = waves < 1 ? 1 : waves > 16 ? 16 : waves;
+    while (waves > 4 && !azd::dense_pool_plan(a, waves, &dyn_stride, &dyn_bytes, &why)) waves -= 1;
     azd::FusedEval fe;
     const bool hashed = e->ev->fused_desc(&fe) && fe.kind == 4; // the test harness' fixed prediction stream, served like a model's rows
-    if (!e->pool_step || !e->persist_enabled || e->pool_failed || e->ext_unsupported || a.KW > 4 || (!a.state_vecs16 && !hashed) ||
+    if (!e->pool_step || !e->persist_enabled || e->pool_failed || e->ext_unsupported || (!a.state_vecs16 && !hashed) ||
         n_calls < 1 || !azd::dense_pool_plan(a, waves, &dyn_stride, &dyn_bytes, &why)) {
         e->step_reason = !e->pool_step || !e->persist_enabled ? "dense-graph space: the pool step is not configured for this engine"
                          : e->pool_failed                      ? "an earlier pool launch of this engine aborted: launch-per-phase form"
-                         : a.KW > 4                            ? "dense-graph space: the pool step's searchers hold up to 256 slots per root (register budget of a 16-wave workgroup)"
                          : ((!a.state_vecs16 && !hashed) || e->ext_unsupported)
                              ? "dense-graph space: the pool step needs an evaluator that serves gathered bf16 rows (ActionModel with bf16 storage)"
                              : why;

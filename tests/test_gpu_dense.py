@@ -106,6 +106,8 @@ def test_dense_parity_n50_reference_tolerances(az, orc):
     (20, 300, 0.2, 5, 60, ([50, 20, 10], 5), 120, 40, 128),
     (50, 96, 0.1, 5, 128, ([200, 50, 50], 25), 100, 50, 128),
     (50, 40, 0.1, 150, 250, ([200, 50, 50], 25), 60, 30, 256),
+    (50, 24, 0.1, 400, 612, ([200, 50, 50], 25), 40, 20, 612),   # the drivers' image: up to E // 2 slots per root
+    (50, 12, 0.08, 700, 1000, ([200, 50, 50], 25), 24, 12, 1024),
 ])
 def test_dense_pool_step_against_the_oracle(az, orc, n, B, p, kmin, kmax, tol, steps, every, slots):
     """the space's CU-resident form: searcher workgroups only, the evaluator outside the kernel.  Trees, state vectors, costs,
@@ -114,24 +116,25 @@ def test_dense_pool_step_against_the_oracle(az, orc, n, B, p, kmin, kmax, tol, s
     assert c["EXPANSIONS"] > 100
 
 
-def test_dense_pool_step_with_the_bf16_model_equals_the_launch_per_phase_form(az, monkeypatch):
+@pytest.mark.parametrize("B,max_slots,kmax", [(640, 128, 128), (256, 612, 612)])
+def test_dense_pool_step_with_the_bf16_model_equals_the_launch_per_phase_form(az, monkeypatch, B, max_slots, kmax):
     """config E's model on the pool step: the rows the searchers post are gathered into the batched bf16 GEMMs (k_gemm16 with row
     lists, whatever batch a row lands in) and scattered back -- same trees, counters, argmin, prediction rows and training step
     as one launch per phase"""
-    n, B, seed, calls = 50, 640, 5, 70
+    n, seed, calls = 50, 5, 70
     tol = ([200, 50, 50], 25)
-    space = az.DenseGraphSpace(n, 0.1)
-    roots = space.generate_roots(seed, B)
+    space = az.DenseGraphSpace(n, 0.1, max_slots=max_slots)
+    roots = space.generate_roots(seed, B, kmin=5, kmax=kmax)
     runs = []
     for pool in (True, False):
         if not pool:
             monkeypatch.setenv("AZD_DENSE_NO_POOL", "1")
         model = az.ActionModel(B, space.STATE_DIM, space.ACTION_DIM, hidden=(512, 512, 512), seed=seed, dtype="bf16")
-        o = az.NablaOptimizer.par_new(space, roots, model, B)
+        o = az.NablaOptimizer.par_new(space, roots, model, B, prediction_capacity=131072)
         imp = o.par_roll_out_episodes(tol, n_calls=calls)
         assert o.step_form()[0] == ("pool" if pool else "per_call_graph"), o.step_form()
         loss = o.par_update_model(3)
-        o.par_reset_trees_policy(seed, 0, 5, 128)
+        o.par_reset_trees_policy(seed, 0, 5, kmax)
         imp2 = o.par_roll_out_episodes(tol, n_calls=30)
         runs.append((o, imp, imp2, loss))
     monkeypatch.delenv("AZD_DENSE_NO_POOL")

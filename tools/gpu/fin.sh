@@ -1,4 +1,3 @@
 cd /root/repo
 timeout -k 10 1000 python -m pytest tests -x -q -m gpu 2>&1 | tail -4 || exit 1
-timeout -k 10 200 python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" 2>&1 | tail -2 || exit 1
-bash tools/refresh_profiles.sh r03 bench stats examples 2>&1 | tail -5
+bash tools/refresh_profiles.sh r03 bench 2>&1 | tail -3
