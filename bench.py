@@ -55,11 +55,13 @@ WORKLOADS = {
                 tol=([200, 200, 100, 100, 50, 50, 25, 25], 10),
                 caps=dict(prediction_capacity=57344), name="Ramsey R(4,4) N=17"),
     # BASELINE configs[4]: the build-defined dense-graph space (oracle/dense_graph.inc), N = 50, G(50, 0.1) roots, 512-wide
-    # model; one launch per phase, replayed from hipGraphs over four sub-populations.  max_slots = the most modifiable edge slots
-    # a root brings (= predictions a node holds): 128 keeps a tree's prediction arena at 2 MB for 8192 agents per GPU; the
-    # drivers' image E // 2 = 612 is built and tested (tests/test_gpu_dense.py) and measured with --max-slots 612 at fewer agents
+    # model, on the pool step with the evaluator's GEMM launches beside the searchers.  max_slots = the most
+    # modifiable edge slots a root brings (= predictions a node holds): config E takes 128 (a tree's prediction arena is 2 MB
+    # then), E612 the drivers' image of E // 2 = 612 slots (the c21 drivers permit up to half of the action space: 04-c21-tree.rs:85)
     "dense50": dict(kind="dense", n=50, p=0.1, agents=8192, hidden=(512, 512, 512), tol=([200, 50, 50], 25), max_slots=128,
                     caps=dict(prediction_capacity=131072), name="dense graphs N=50"),
+    "dense50x612": dict(kind="dense", n=50, p=0.1, agents=8192, hidden=(512, 512, 512), tol=([200, 50, 50], 25), max_slots=612,
+                        caps=dict(prediction_capacity=524288), name="dense graphs N=50"),
 }
 # BASELINE.json configs[0..3] as presets: (workload, agents per GPU, evaluator storage)
 CONFIGS = {
@@ -67,7 +69,8 @@ CONFIGS = {
     "B": ("c21", 4096, "f32"),     # configs[1]: the metric's configuration on one GPU
     "C": ("c21", 8192, "bf16"),    # configs[2]: 65536 agents over 8 GPUs, bf16 MLP, RCCL all-gather
     "D": ("r44", 8192, "f32"),     # configs[3]: 32768 agents over 4 GPUs, Ramsey space
-    "E": ("dense50", 8192, "bf16"),  # configs[4]: N = 50 dense graphs, 512-wide bf16 MLP on MFMA, hipGraph-replayed step
+    "E": ("dense50", 8192, "bf16"),  # configs[4]: N = 50 dense graphs, 512-wide bf16 MLP on MFMA
+    "E612": ("dense50x612", 8192, "bf16"),  # the same with roots of up to E // 2 = 612 modifiable slots
 }
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 

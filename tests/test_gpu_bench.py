@@ -40,3 +40,9 @@ def test_bench_line_of_config_e_on_the_pool_searchers():
     assert "outside the kernel" in j["evaluator_form"]
     assert j["roofline"]["kernel"] == "k_pool_search<2>" and j["value"] > 1e5
     assert "128" in j["config"]["workload"]  # the slot cap is stated
+
+
+def test_bench_line_of_config_e_with_the_drivers_slot_range():
+    j = bench("--config", "E612", "--agents", "512", "--steps", "20", "--warmup", "10", "--no-cpu-baseline")
+    assert j["step_form"] == "pool" and j["roofline"]["kernel"] == "k_pool_search<10>" and j["value"] > 1e4
+    assert "612" in j["config"]["workload"]

@@ -16,7 +16,7 @@ if has bench; then
   timeout -k 10 400 python bench.py --config E --steps 400 --warmup 50 > $O/bench_E.log 2>&1
   AZD_DENSE_NO_POOL=1 timeout -k 10 400 python bench.py --config E --steps 400 --warmup 50 --no-cpu-baseline > $O/bench_E_per_call.log 2>&1
   timeout -k 10 400 python bench.py --config E --no-cpu-baseline > $O/bench_E_epochs.log 2>&1
-  timeout -k 10 400 python bench.py --config E --steps 200 --warmup 50 --agents 8192 --max-slots 612 --prediction-capacity 524288 --no-cpu-baseline > $O/bench_E612.log 2>&1
+  timeout -k 10 400 python bench.py --config E612 --steps 200 --warmup 50 --no-cpu-baseline > $O/bench_E612.log 2>&1
   echo benches done
 fi
 if has stats; then
