@@ -129,15 +129,15 @@ int dense_pool_search_resident(const Arenas &a, int waves, size_t dyn_bytes) { /
     DISPATCH_DKW(a, q_pool_search_resident, &nb, waves, dyn_bytes);
     return nb;
 }
-void launch_ext_take(const PoolArgs &pool, uint32_t *rows, uint32_t *home, uint32_t *n, void *stream) {
-    k_ext_take<<<dim3(1), dim3(POOL_XCDS * 64), 0, (hipStream_t)stream>>>(pool, rows, home, n);
+void launch_ext_take(const PoolArgs &pool, uint32_t *rows, uint32_t *home, uint32_t *n, unsigned long long *t0, void *stream) {
+    k_ext_take<<<dim3(1), dim3(POOL_XCDS * 64), 0, (hipStream_t)stream>>>(pool, rows, home, n, t0);
 }
 void launch_ext_hash_rows(const PersistArgs *d_args, const uint32_t *rows, const uint32_t *n, uint32_t cap, float *h_theta, void *stream) {
     k_ext_hash_rows<<<dim3(cap), dim3(256), 0, (hipStream_t)stream>>>(d_args, rows, n, h_theta);
 }
 void launch_ext_deliver(const PoolArgs &pool, const Arenas &a, const uint32_t *rows, const uint32_t *home, const uint32_t *n, uint32_t cap,
-                        void *stream) {
-    k_ext_deliver<<<dim3((cap + 255) / 256), dim3(256), 0, (hipStream_t)stream>>>(pool, a, rows, home, n);
+                        const unsigned long long *t0, void *stream) {
+    k_ext_deliver<<<dim3((cap + 255) / 256), dim3(256), 0, (hipStream_t)stream>>>(pool, a, rows, home, n, t0);
 }
 
 } // namespace azd

@@ -168,6 +168,7 @@ struct azd_engine {
     int ext_graph_n = 0;
     bool ext_unsupported = false;     // the evaluator cannot serve gathered rows from device-side lists (asked once)
     uint32_t *d_ext_rows = nullptr, *d_ext_home = nullptr, *d_ext_n = nullptr; // [EXT_STREAMS][B], [EXT_STREAMS][B], [EXT_STREAMS]
+    unsigned long long *d_ext_t0 = nullptr; // [EXT_STREAMS] when the batch in hand was collected (PoolCtl::eval_busy)
     int ext_depth = 2;
     hipEvent_t ext_done = nullptr, ext_fork = nullptr, ext_ring[EXT_STREAMS][EXT_IN_FLIGHT] = {};
     unsigned long long ext_iterations = 0; // evaluator graph replays of the last dense pool launch (diagnostics)
@@ -803,6 +804,7 @@ int azd_engine_create(azd_engine **out, const azd_engine_config *cfg, azd_evalua
             TRY(e->alloc(&e->d_ext_rows, B * azd_engine::EXT_STREAMS));
             TRY(e->alloc(&e->d_ext_home, B * azd_engine::EXT_STREAMS));
             TRY(e->alloc(&e->d_ext_n, (size_t)azd_engine::EXT_STREAMS));
+            TRY(e->alloc(&e->d_ext_t0, (size_t)azd_engine::EXT_STREAMS));
         }
     }
     e->log_calls = 1024;
@@ -1105,10 +1107,10 @@ static int dense_pool_run(azd_engine *e, const azd::TolTable &t, int n_calls, bo
             int st_g = AZD_OK;
             // several rounds per graph: between two graphs on a stream the GPU idles ~18 us, between two kernels of one graph not at all
             for (int r = 0; r < rounds && st_g == AZD_OK; ++r) {
-                azd::launch_ext_take(pool, rows, home, cnt, e->ext_stream[x]);
+                azd::launch_ext_take(pool, rows, home, cnt, e->d_ext_t0 + x, e->ext_stream[x]);
                 if (hashed) azd::launch_ext_hash_rows(e->d_pargs, rows, cnt, (uint32_t)a.B, a.h_theta, e->ext_stream[x]);
                 else st_g = e->ev->write_predictions_gathered(rows, cnt, a.B, a.state_vecs16, a.S16, a.h_theta, e->ext_stream[x], x * a.B);
-                azd::launch_ext_deliver(pool, a, rows, home, cnt, (uint32_t)a.B, e->ext_stream[x]);
+                azd::launch_ext_deliver(pool, a, rows, home, cnt, (uint32_t)a.B, e->d_ext_t0 + x, e->ext_stream[x]);
             }
             const hipError_t he = hipStreamEndCapture(e->ext_stream[x], &g);
             if (st_g) {
@@ -1204,8 +1206,10 @@ static int dense_pool_run(azd_engine *e, const azd::TolTable &t, int n_calls, bo
         if (st) return st;
         if (e->h_status->pool_ticks > 0) {
             const double T = (double)e->h_status->pool_ticks;
-            e->pool_util_eval = 0.0;
+            e->pool_util_eval = (double)e->h_status->pool_eval_busy / (T * n_ext); // the share of the launch an evaluator stream held a batch
             e->pool_util_search = (double)e->h_status->pool_search_busy / (T * e->pool_search_waves);
+            // (A controller on these two shares, as for the in-kernel evaluator, was measured and not kept: over whole epochs the rate is flat
+            // between 112 and 160 searcher workgroups -- config E 19.7-20.0 M expansions/s, 612-slot roots 10.2-10.3 M.)
         }
         if (e->h_status->pool_abort) {
             // no other CU-resident form exists for this space to take the launch over; the trees stand between calls, but

@@ -336,10 +336,10 @@ bool dense_pool_plan(const Arenas &a, int waves, uint32_t *dyn_stride, size_t *d
 void dense_launch_pool_search(const Arenas &a, const PersistArgs *d_args, const StepLaunch &sl, int n_blocks, int waves, uint32_t dyn_stride,
                               size_t dyn_bytes, void *stream);
 int dense_pool_search_resident(const Arenas &a, int waves, size_t dyn_bytes);
-void launch_ext_take(const PoolArgs &pool, uint32_t *rows, uint32_t *home, uint32_t *n, void *stream);
+void launch_ext_take(const PoolArgs &pool, uint32_t *rows, uint32_t *home, uint32_t *n, unsigned long long *t0, void *stream);
 void launch_ext_hash_rows(const PersistArgs *d_args, const uint32_t *rows, const uint32_t *n, uint32_t cap, float *h_theta, void *stream);
 void launch_ext_deliver(const PoolArgs &pool, const Arenas &a, const uint32_t *rows, const uint32_t *home, const uint32_t *n, uint32_t cap,
-                        void *stream);
+                        const unsigned long long *t0, void *stream);
 void launch_persist(const Arenas &a, const PersistArgs *d_args, const StepLaunch &sl,
                     uint32_t *log_node, uint32_t dyn_stride, size_t dyn_bytes, void *stream);
 void launch_c21_modify_roots(const Arenas &a, uint64_t seed, uint64_t epoch, uint64_t first_agent, int kmin, int kmax,

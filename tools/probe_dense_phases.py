@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """Diagnostic (make PROFILE=1 build, AZD_LIB=azdopt_amd/libazdopt_amd_prof.so): where a searcher wave's time goes per call of the
-dense-graph workload (config E), from the in-kernel phase stamps (100 MHz ticks, summed over agents)."""
+dense-graph workload (config E), from the in-kernel phase stamps (100 MHz ticks, summed over agents).
+    python tools/probe_dense_phases.py [agents 8192] [max_slots 128]"""
 import os
 import sys
 import time
@@ -8,10 +9,11 @@ import time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import azdopt_amd as az  # noqa: E402
 
-B, calls = 8192, 400
-space = az.DenseGraphSpace(50, 0.1)
+B, calls = (int(sys.argv[1]) if len(sys.argv) > 1 else 8192), 400
+slots = int(sys.argv[2]) if len(sys.argv) > 2 else 128
+space = az.DenseGraphSpace(50, 0.1, max_slots=slots)
 model = az.ActionModel(B, space.STATE_DIM, space.ACTION_DIM, hidden=(512, 512, 512), seed=0, dtype="bf16")
-opt = az.NablaOptimizer.par_new(space, space.generate_roots(0, B), model, B, prediction_capacity=131072)
+opt = az.NablaOptimizer.par_new(space, space.generate_roots(0, B), model, B, prediction_capacity=131072 if slots <= 128 else 524288)
 opt.par_roll_out_episodes(([200, 50, 50], 25), n_calls=50)
 c0 = opt.counters()
 t0 = time.perf_counter()
