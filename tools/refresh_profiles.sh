@@ -17,6 +17,7 @@ if has bench; then
   AZD_DENSE_NO_POOL=1 timeout -k 10 400 python bench.py --config E --steps 400 --warmup 50 --no-cpu-baseline > $O/bench_E_per_call.log 2>&1
   timeout -k 10 400 python bench.py --config E --no-cpu-baseline > $O/bench_E_epochs.log 2>&1
   timeout -k 10 400 python bench.py --config E612 --steps 200 --warmup 50 --no-cpu-baseline > $O/bench_E612.log 2>&1
+  timeout -k 10 400 python bench.py --config E612 --no-cpu-baseline > $O/bench_E612_epochs.log 2>&1
   echo benches done
 fi
 if has stats; then

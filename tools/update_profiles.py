@@ -84,7 +84,7 @@ for src, dst in (("prof/**/*kernel_stats.csv", "_pool_kernel_stats.csv"), ("prof
         for row in csv.DictReader(open(f)):
             if any(k in row["Name"] for k in ("k_pool", "k_gemm16", "k_rollout", "k_gemm_bf16", "k_ext_")):
                 print("rocprofv3 %-28s %-60s launches %5s avg ms %.4f" % (dst, row["Name"][:60], row["Calls"], float(row["AverageNs"]) / 1e6))
-names = ("default", "driver20", "B_async", "A", "C", "D", "B8192", "E", "E_epochs", "E_per_call", "E612")
+names = ("default", "driver20", "B_async", "A", "C", "D", "B8192", "E", "E_epochs", "E_per_call", "E612", "E612_epochs")
 with open(os.path.join(P, R + "_bench_lines.txt"), "w") as f:
     for name in names:
         line = bench_line(name)
