@@ -193,6 +193,7 @@ struct azd_engine {
     // moves the evaluators' share by 100 workgroups per unit of (u_e - u_s - target), target 0 .. 0.06 by how crowded the waves are.
     struct {
         int n_eval = 0; // what the next launch takes (0: the first guess)
+        int updates = 0; // launches the controller has acted on
     } pool_fb;
     // Run-ahead window (azd_engine_run_ahead): one pool launch of n calls is under way, or over, and par_roll_out_episodes hands
     // its calls out one by one from what the kernel publishes (PoolArgs::win_*) instead of launching anything.
@@ -1487,7 +1488,11 @@ static int roll_out_impl(azd_engine *e, const azd::TolTable &t, int n_calls, int
             // a slightly starved evaluator side fills 32-row batches, which cost it a quarter less per row)
             const double crowd = e->pool_search_waves > 0 ? (double)e->a.B / e->pool_search_waves - 1.5 : 0.0;
             const double d = e->pool_util_eval - e->pool_util_search - 0.06 * (crowd < 0 ? 0.0 : crowd > 1 ? 1.0 : crowd);
-            const int cur = e->pool_eval_wgs, lim = cur / 4 > 4 ? cur / 4 : 4;
+            // (large steps while the first guess is being corrected; afterwards at most 6 workgroups per launch, so that one disturbed
+            // launch -- another tenant's burst on the box, a first dispatch under a profiler -- cannot carry the split far: a run whose
+            // warm-up launch moved it from 89 to 102 evaluators stayed 7 % low for the two launches it had left to walk back)
+            const int cur = e->pool_eval_wgs, lim = e->pool_fb.updates < 2 ? (cur / 4 > 4 ? cur / 4 : 4) : 6;
+            e->pool_fb.updates += 1;
             int mv = (int)(100.0 * d + (d >= 0 ? 0.5 : -0.5));
             mv = mv > lim ? lim : mv < -lim ? -lim : mv;
             int next = cur + mv;
