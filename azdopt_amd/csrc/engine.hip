@@ -1383,7 +1383,8 @@ static int roll_out_impl(azd_engine *e, const azd::TolTable &t, int n_calls, int
         if (!use_async && !use_barrier && *why_b) e->step_reason += std::string("; ") + why_b;
     }
     e->step_form = use_pool ? AZD_STEP_POOL : use_async ? AZD_STEP_ASYNC : use_barrier ? AZD_STEP_BARRIER : AZD_STEP_PER_CALL;
-    if (!dense_reason.empty()) e->step_reason = dense_reason; // (why the space's pool step did not run: the launch-per-phase form follows)
+    if (e->a.space == azd::SPACE_DENSE) // why the space's pool step did not run: the launch-per-phase form follows
+        e->step_reason = dense_reason.empty() ? "AZD_DENSE_NO_POOL: the dense-graph space's pool step was switched off" : dense_reason;
     if (ahead) { // only the pool step publishes its calls while it runs, one launch's worth of them
         const bool ok = use_pool && fe.kind >= 3 && n_calls >= 1 && n_calls <= e->log_calls && !e->timing;
         if (!ok) return AZD_OK; // a hint: the calls run when they are asked for

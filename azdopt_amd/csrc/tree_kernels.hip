@@ -111,7 +111,7 @@ bool pool_plan(const Arenas &a, const FusedEval &ev, PoolArgs *pool, uint32_t *d
     const char *dummy;
     if (!why) why = &dummy;
     if (a.space == SPACE_DENSE) {
-        *why = "dense-graph space: launch-per-phase form only (its state vector does not fit the CU-resident forms)";
+        *why = "dense-graph space: its CU-resident form is the pool searchers with the evaluator outside the kernel (engine.hip: dense_pool_run)";
         return false;
     }
     if (a.space == SPACE_RAMSEY) return ramsey_pool_plan(a, ev, pool, dyn_stride, dyn_bytes, why);
@@ -140,7 +140,7 @@ bool async_plan(const Arenas &a, const FusedEval &ev, uint32_t *dyn_stride, size
     const char *dummy;
     if (!why) why = &dummy;
     if (a.space == SPACE_DENSE) {
-        *why = "dense-graph space: launch-per-phase form only (its state vector does not fit the CU-resident forms)";
+        *why = "dense-graph space: its CU-resident form is the pool searchers with the evaluator outside the kernel (engine.hip: dense_pool_run)";
         return false;
     }
     if (a.space == SPACE_RAMSEY) return ramsey_async_plan(a, ev, dyn_stride, dyn_bytes, why);
@@ -302,7 +302,7 @@ bool persist_plan(const Arenas &a, const FusedEval &ev, uint32_t *dyn_stride, si
     size_t stride = (dyn_lds_bytes(a.n) + 15) & ~(size_t)15;
     size_t total = stride * PERSIST_WAVES;
     if (a.space == SPACE_DENSE) {
-        *why = "dense-graph space: launch-per-phase form only (its state vector does not fit the CU-resident forms)";
+        *why = "dense-graph space: its CU-resident form is the pool searchers with the evaluator outside the kernel (engine.hip: dense_pool_run)";
         return false;
     }
     if (a.space == SPACE_RAMSEY) return ramsey_persist_plan(a, ev, dyn_stride, dyn_bytes, why);
