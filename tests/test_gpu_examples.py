@@ -38,14 +38,17 @@ def test_ramsey_driver_writes_the_reference_scalars(tmp_path):
     assert tags.count("loss") == 2 and {"clique_counts/0", "clique_counts/1"} <= set(tags)
 
 
-def test_cpp_host_drives_the_same_engine(tmp_path):
+@pytest.mark.parametrize("batch,stride", [(64, 20), (256, 1)])
+def test_cpp_host_drives_the_same_engine(tmp_path, batch, stride):
     """examples/c21_tree.cpp over include/azdopt_amd.hpp (a compiled host on the C ABI) and the Python host run the same
-    two epochs: same losses, same best evaluation and lambda_1 line by line"""
+    two epochs: same losses, same best evaluation and lambda_1 line by line.  256 agents at stride 1 = the reference's
+    call-by-call loop on the pool step, which the compiled host answers from a run-ahead window (one launch per epoch); the
+    Python host beside it makes a launch per call."""
     import azdopt_amd as az
     exe = tmp_path / "c21_tree"
     subprocess.run(["g++", "-O1", "-std=c++17", "-I" + os.path.join(ROOT, "include"), os.path.join(ROOT, "examples", "c21_tree.cpp"), "-o", str(exe),
                     "-L" + os.path.join(ROOT, "azdopt_amd"), "-lazdopt_amd", "-Wl,-rpath," + os.path.join(ROOT, "azdopt_amd")], check=True, timeout=300)
-    epochs, episodes, batch, stride, seed, hidden = 2, 60, 64, 20, 3, [64, 64]
+    epochs, episodes, seed, hidden = 2, 60, 3, [64, 64]
     r = subprocess.run([str(exe), str(epochs), str(episodes), str(batch), str(stride), str(seed)] + [str(h) for h in hidden],
                        capture_output=True, text=True, timeout=300, check=True)
     lines = r.stdout.splitlines()
@@ -69,6 +72,8 @@ def test_cpp_host_drives_the_same_engine(tmp_path):
             done += stride
             if improved:
                 show(opt.argmin_data())
+        if batch >= 256:
+            assert opt.step_form()[0] == "pool"
         want.append("==== EPISODE: %d ====" % episodes)
         want.append("loss: %.9g" % opt.par_update_model(200))
         opt.par_reset_trees_policy(seed, epoch, kmin, kmax)
