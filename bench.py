@@ -208,6 +208,9 @@ def main():
     rehearse = os.environ.get("AZD_BENCH_REHEARSE") == "1"
     if rehearse:
         local_rank = 0
+        # the ranks share ONE GPU here: the dense-graph space's searcher workgroups of all ranks together must leave CUs to the
+        # GEMM launches (a rank with a GPU of its own takes half the chip)
+        os.environ.setdefault("AZD_DENSE_POOL_SEARCH_WGS", str(max(8, 96 // max(1, world))))
     torch.cuda.set_device(local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
