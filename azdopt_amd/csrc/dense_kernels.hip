@@ -132,6 +132,39 @@ int dense_pool_search_resident(const Arenas &a, int waves, size_t dyn_bytes) { /
 void launch_ext_take(const PoolArgs &pool, uint32_t *rows, uint32_t *home, uint32_t *n, unsigned long long *t0, void *stream) {
     k_ext_take<<<dim3(1), dim3(POOL_XCDS * 64), 0, (hipStream_t)stream>>>(pool, rows, home, n, t0);
 }
+// ---------------------------------------------------------------- recovery of an aborted pool launch by the launch-per-phase kernels
+// resume[t] = calls agent t has completed | 1u << 31 if its last call ended on a node whose prediction row is still due (k_pool_resume_scan)
+__global__ void k_park(Arenas a, const uint32_t *__restrict__ resume, const int n_calls, const int round, const int park) {
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= a.B) return;
+    uint32_t f = a.flags[t] & ~(uint32_t)FLAG_PARKED;
+    if (park) {
+        const uint32_t r = resume[t];
+        const bool sits_out = round < 0 ? (r >> 31) == 0u : (int)(r & 0x7FFFFFFFu) + round >= n_calls;
+        if (sits_out) f |= (uint32_t)FLAG_PARKED;
+    }
+    a.flags[t] = f;
+}
+void launch_park(const Arenas &a, const uint32_t *resume, int n_calls, int round, int park, void *stream) {
+    k_park<<<dim3((a.B + 255) / 256), dim3(256), 0, (hipStream_t)stream>>>(a, resume, n_calls, round, park);
+}
+// the candidates of the agents that took part in round r, each under the call it really was (optimizer/mod.rs:194-246 up to the choice among trees)
+__global__ void k_log_candidates_resume(Arenas a, unsigned long long *__restrict__ log_key, const uint32_t *__restrict__ resume, const int n_calls,
+                                        const int round) {
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= a.B) return;
+    const uint32_t node = a.cand_node[t];
+    const int call = (int)(resume[t] & 0x7FFFFFFFu) + round;
+    if (node != NONE && a.flags[t] == 0 && call < n_calls) {
+        const unsigned long long key = ((unsigned long long)ordf(a.cand_c[t]) << 32) | ((unsigned long long)((uint32_t)t & 0xFFFFu) << 16) |
+                                       (unsigned long long)(node & 0xFFFFu);
+        atomicMin(&log_key[call], key);
+        a.cand_node[t] = NONE; // num_inspected_nodes = nodes.len()
+    }
+}
+void launch_log_candidates_resume(const Arenas &a, unsigned long long *log_key, const uint32_t *resume, int n_calls, int round, void *stream) {
+    k_log_candidates_resume<<<dim3((a.B + 255) / 256), dim3(256), 0, (hipStream_t)stream>>>(a, log_key, resume, n_calls, round);
+}
 void launch_ext_hash_rows(const PersistArgs *d_args, const uint32_t *rows, const uint32_t *n, uint32_t cap, float *h_theta, void *stream) {
     k_ext_hash_rows<<<dim3(cap), dim3(256), 0, (hipStream_t)stream>>>(d_args, rows, n, h_theta);
 }

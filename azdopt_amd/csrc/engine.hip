@@ -1026,8 +1026,10 @@ static int pool_finish_launch(azd_engine *e, const azd::FusedEval &fe, const azd
 // replayed from a graph on a second stream for as long as the searchers run.  Agents advance independently, so a launch no longer
 // lasts as long as its slowest agent per call (launch-per-phase form: a roll-out launch took 1.2 ms where the mean agent needed 0.06).
 // *ran = false: the form cannot run here (why in e->step_reason) and the caller takes the launch-per-phase form.
-static int dense_pool_run(azd_engine *e, const azd::TolTable &t, int n_calls, bool *ran) {
+// *left_out: calls still to run when an aborted launch had to be completed by the launch-per-phase kernels (the caller runs them).
+static int dense_pool_run(azd_engine *e, const azd::TolTable &t, int n_calls, bool *ran, int *left_out) {
     *ran = false;
+    *left_out = 0;
     const azd::Arenas &a = e->a;
     const char *why = "";
     uint32_t dyn_stride = 0;
@@ -1084,6 +1086,7 @@ static int dense_pool_run(azd_engine *e, const azd::TolTable &t, int n_calls, bo
     pool.eval_stride = pool.eval_out_off = 0;
     pool.eval_rows = 0;
     pool.debug_abort_call = 0;
+    if (const char *env = getenv("AZD_POOL_DEBUG_ABORT_CALL")) pool.debug_abort_call = (uint32_t)atoi(env); // test hook: k_ext_deliver
     // the evaluator's graphs, one per stream: collect, the layers over the collected rows, hand back.  Every stream may find the
     // whole population posted, so each has row lists and activation rows of its own.
     if (!hashed) {
@@ -1213,13 +1216,63 @@ static int dense_pool_run(azd_engine *e, const azd::TolTable &t, int n_calls, bo
             // between 112 and 160 searcher workgroups -- config E 19.7-20.0 M expansions/s, 612-slot roots 10.2-10.3 M.)
         }
         if (e->h_status->pool_abort) {
-            // no other CU-resident form exists for this space to take the launch over; the trees stand between calls, but
-            // agents have made different numbers of them
+            // A wait ran into its bound (nothing made progress for 4 s: the GEMM launches never got CUs, say).  The trees are
+            // consistent -- a wave never leaves an agent inside a call -- but the agents stand at different calls.  No other
+            // CU-resident form of this space exists to take the launch over, so the launch-per-phase kernels complete it: agent by
+            // agent from where each one stands (k_pool_resume_scan), the ones that are through sitting out (FLAG_PARKED), every
+            // candidate logged under the call it really belongs to, one replay of the log at the end -- the results of an
+            // undisturbed launch.  This engine stays with the launch-per-phase form.
             e->pool_failed = true;
             e->log_clean = false;
-            azd::g_last_error = "dense pool step: a queue wait ran into its bound (no searcher or evaluator launch made progress); "
-                                "this engine takes the launch-per-phase form from here on";
-            return AZD_ERR_UNREACHABLE;
+            azd::launch_pool_resume_scan(a, pool, k, e->d_resume, e->stream);
+            std::vector<uint32_t> res((size_t)a.B);
+            AZD_HIP(hipMemcpyAsync(res.data(), e->d_resume, res.size() * 4, hipMemcpyDeviceToHost, e->stream));
+            AZD_HIP(hipStreamSynchronize(e->stream));
+            st = pool_clear(e, pool);
+            if (st) return st;
+            int rounds = 0;
+            bool any_pending = false;
+            for (uint32_t r : res) {
+                const int rem = k - (int)(r & 0x7FFFFFFFu);
+                rounds = rem > rounds ? rem : rounds;
+                any_pending = any_pending || (r >> 31) != 0u;
+            }
+            auto evaluate_rows = [&]() -> int {
+                if (hashed) { // the fixed stream's rows depend on the call: not reproducible outside the launch that posted them
+                    azd::g_last_error = "dense pool step aborted with the test harness' prediction stream: no recovery";
+                    return AZD_ERR_UNREACHABLE;
+                }
+                const uint64_t calls_before = e->ev->calls;
+                const int s2 = e->ev->write_predictions_dev16(a.B, a.state_vecs, a.state_vecs16, a.S16, a.h_theta, e->stream);
+                e->ev->calls = calls_before;
+                return s2;
+            };
+            if (any_pending) { // the rows that were still due, and add_actions for the nodes waiting for them
+                azd::launch_park(a, e->d_resume, k, -1, 1, e->stream);
+                st = evaluate_rows();
+                if (st) return st;
+                azd::launch_add_actions(a, 0, e->stream);
+            }
+            for (int r = 0; r < rounds; ++r) {
+                azd::launch_park(a, e->d_resume, k, r, 1, e->stream);
+                azd::launch_rollout(a, t, e->stream);
+                st = evaluate_rows();
+                if (st) return st;
+                azd::launch_add_actions(a, 0, e->stream);
+                azd::launch_log_candidates_resume(a, e->d_log_key, e->d_resume, k, r, e->stream);
+            }
+            azd::launch_park(a, e->d_resume, k, 0, 0, e->stream); // everyone back
+            azd::launch_argmin_log(a, k, e->d_log_key, e->stream);  // replays the k calls and leaves the log clean
+            e->log_clean = true;
+            AZD_HIP(hipGetLastError());
+            st = fetch_status(e);
+            if (st) return st;
+            e->step_form = AZD_STEP_PER_CALL;
+            e->step_reason = "dense pool step aborted (a queue wait ran into its bound: the searchers or the evaluator's launches made no "
+                             "progress); the launch-per-phase kernels completed the launch and serve this engine from here on";
+            *ran = true;
+            *left_out = left;
+            return AZD_OK;
         }
     }
     *ran = true;
@@ -1234,14 +1287,16 @@ static int roll_out_impl(azd_engine *e, const azd::TolTable &t, int n_calls, int
     if (e->a.space == azd::SPACE_DENSE && !getenv("AZD_DENSE_NO_POOL")) {
         if (ahead) return AZD_OK; // (the evaluator's launches need this thread: nothing can run ahead of the host)
         bool ran = false;
-        st = dense_pool_run(e, t, n_calls, &ran);
+        int left_after = 0;
+        st = dense_pool_run(e, t, n_calls, &ran, &left_after);
         if (st) return st;
-        if (ran) {
+        if (ran && left_after == 0) {
             st = check_status(e);
             if (improved) *improved = (int)(e->h_status->improved - e->seen_improved);
             e->seen_improved = e->h_status->improved;
             return st;
         }
+        if (ran) n_calls = left_after; // (an aborted launch was completed call by call: what is left runs the same way, below)
     }
     const std::string dense_reason = e->a.space == azd::SPACE_DENSE ? e->step_reason : std::string();
     azd::FusedEval fe;

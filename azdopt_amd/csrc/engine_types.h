@@ -66,6 +66,9 @@ enum : uint32_t {
     FLAG_UNREACHABLE = 1u << 5,
     FLAG_NODE_ACTIONS = 1u << 6,
     FLAG_LOOP_GUARD = 1u << 7,
+    // not a failure: the agent sits out the launches of a recovery round (engine.hip: an aborted dense pool launch is completed by
+    // the launch-per-phase kernels, agent by agent from where each one stands); set and cleared by k_park
+    FLAG_PARKED = 1u << 30,
 };
 
 struct ArgminRec { // device copy of azd_argmin
@@ -337,6 +340,10 @@ void dense_launch_pool_search(const Arenas &a, const PersistArgs *d_args, const 
                               size_t dyn_bytes, void *stream);
 int dense_pool_search_resident(const Arenas &a, int waves, size_t dyn_bytes);
 void launch_ext_take(const PoolArgs &pool, uint32_t *rows, uint32_t *home, uint32_t *n, unsigned long long *t0, void *stream);
+// recovery of an aborted dense pool launch (engine.hip): park (round >= 0: the agents whose calls are through by that round; -1: the
+// agents that are not waiting for a row) / unpark (mode 0), and the candidates of round r under the call each agent is really in
+void launch_park(const Arenas &a, const uint32_t *resume, int n_calls, int round, int park, void *stream);
+void launch_log_candidates_resume(const Arenas &a, unsigned long long *log_key, const uint32_t *resume, int n_calls, int round, void *stream);
 void launch_ext_hash_rows(const PersistArgs *d_args, const uint32_t *rows, const uint32_t *n, uint32_t cap, float *h_theta, void *stream);
 void launch_ext_deliver(const PoolArgs &pool, const Arenas &a, const uint32_t *rows, const uint32_t *home, const uint32_t *n, uint32_t cap,
                         const unsigned long long *t0, void *stream);

@@ -414,7 +414,8 @@ void *azd_engine_stream(azd_engine *e); /* hipStream_t the engine launches on */
  * The pool step needs its searcher and evaluator workgroups resident together: the grid is clamped to what the occupancy query
  * reports, a device without room for one of each runs the asynchronous step, and a pool launch whose waits run into their
  * bound (4 s without progress) is TAKEN OVER by the asynchronous step where every agent stands -- same results, the call
- * succeeds, *reason says so and the engine stays with the asynchronous step. */
+ * succeeds, *reason says so and the engine stays with the asynchronous step (dense-graph space, whose evaluator runs beside the
+ * kernel: completed by the launch-per-phase kernels in the same way, and the engine stays with those). */
 #define AZD_STEP_NONE 0
 #define AZD_STEP_ASYNC 1
 #define AZD_STEP_BARRIER 2

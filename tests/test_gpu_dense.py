@@ -152,6 +152,49 @@ def test_dense_pool_step_with_the_bf16_model_equals_the_launch_per_phase_form(az
     assert np.array_equal(o0.predictions().view(np.uint32), o1.predictions().view(np.uint32))
 
 
+@pytest.mark.parametrize("n,abort_at,calls", [(20, 3, 60), (12, 40, 1100)])
+def test_dense_pool_abort_is_completed_by_the_launch_per_phase_kernels(az, monkeypatch, n, abort_at, calls):
+    """the abort flag of a dense pool launch (test hook: raised behind the k-th batch the evaluator hands back) no longer fails the
+    call: the launch-per-phase kernels complete the launch agent by agent from where each one stands -- some through all their calls,
+    some waiting for a row that will not come, some never taken -- with the results of an undisturbed run; 1100 calls = a second
+    chunk of the log, which the launch-per-phase form runs too"""
+    B, seed = 300, 11
+    tol = ([50, 20, 10], 5)
+    space = az.DenseGraphSpace(n, 0.2)
+    # (the long case: roots with few slots -- small trees that are exhausted long before the calls are, so that the cascade's frontier stays narrow)
+    roots = space.generate_roots(seed, B, kmin=3, kmax=7) if calls > 800 else space.generate_roots(seed, B)
+    caps = {}
+
+    def mk():
+        model = az.ActionModel(B, space.STATE_DIM, space.ACTION_DIM, hidden=(128, 128), seed=seed, dtype="bf16")
+        return az.NablaOptimizer.par_new(space, roots, model, B, pool_step=True, **caps)
+
+    monkeypatch.setenv("AZD_DENSE_NO_POOL", "1")
+    ref = mk()
+    imp_ref = ref.par_roll_out_episodes(tol, n_calls=calls)
+    monkeypatch.delenv("AZD_DENSE_NO_POOL")
+    monkeypatch.setenv("AZD_POOL_DEBUG_ABORT_CALL", str(abort_at))
+    opt = mk()
+    imp = opt.par_roll_out_episodes(tol, n_calls=calls)
+    form, why = opt.step_form()
+    assert form.startswith("per_call") and "aborted" in why, (form, why)
+    monkeypatch.delenv("AZD_POOL_DEBUG_ABORT_CALL")
+    assert imp == imp_ref
+    c0, c1 = opt.counters(), ref.counters()
+    for k in MAIN_CTRS:
+        assert c0[k] == c1[k], k
+    for i in range(B):
+        assert_tree_equal(opt.get_tree(i), ref.get_tree(i), f"agent {i}")
+    a0, a1 = opt.argmin_data(), ref.argmin_data()
+    assert a0.eval == a1.eval and a0.agent == a1.agent and a0.node == a1.node
+    assert np.array_equal(opt.state_vecs(), ref.state_vecs())
+    # usable afterwards, on the launch-per-phase form
+    assert opt.par_roll_out_episodes(tol, n_calls=10) == ref.par_roll_out_episodes(tol, n_calls=10)
+    assert opt.step_form()[0].startswith("per_call")
+    for i in range(0, B, 11):
+        assert_tree_equal(opt.get_tree(i), ref.get_tree(i), f"agent {i} afterwards")
+
+
 def test_dense_roots_are_validated(az):
     space = az.DenseGraphSpace(12, 0.3)
     model = az.TrivialModel(space.STATE_DIM, space.ACTION_DIM)
