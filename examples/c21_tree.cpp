@@ -7,6 +7,7 @@
 // Differences forced by the boundary: the `init_states` / `modify_root` closures are the seeded built-ins, and `stride`
 // calls are asked for between two looks at ArgminImprovement (stride 1 = the reference's call-by-call loop; the epoch's calls
 // run ahead of the loop in one launch, NablaOptimizer::run_ahead).
+#include <chrono>
 #include <cstdio>
 #include <cstdlib>
 #include <vector>
@@ -54,6 +55,7 @@ int main(int argc, char **argv) {
         auto opt = azdopt::NablaOptimizer<azdopt::ROTModifyParentsOnce>::par_new(space, roots, model, batch, 0, 0, 0, cap(4096, episodes + 64),
                                                                                  cap(8192, 3 * episodes + 64), cap(32768, (episodes + 1) * kmax + 128));
         if (process_argmin(opt.argmin_data())) return 0;
+        const auto t_start = std::chrono::steady_clock::now();
         const azdopt::Tolerance n_as_tol = {{200, 50, 50}, 25}; // :134-136
         const uint32_t n_obs_tol = 200;
         for (int epoch = 1; epoch <= epochs; ++epoch) {
@@ -74,6 +76,10 @@ int main(int argc, char **argv) {
         }
         const auto form = opt.step_form();
         std::printf("step form %d %s\n", form.first, form.second.c_str());
+        // (not in the reference's output) what the loop above cost: node expansions over the wall time since par_new
+        const double secs = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_start).count();
+        const unsigned long long expansions = opt.counters()[AZD_CTR_EXPANSIONS];
+        std::printf("expansions %llu in %.3f s: %.2f M expansions/s (stride %d)\n", expansions, secs, (double)expansions / secs / 1e6, stride);
     } catch (const azdopt::Error &e) {
         std::fprintf(stderr, "azdopt error %d: %s\n", e.status(), e.what());
         return 1;

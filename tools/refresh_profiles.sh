@@ -54,8 +54,8 @@ fi
 if has examples; then
   g++ -O2 -std=c++17 -Iinclude examples/c21_tree.cpp -o $O/c21_tree -Lazdopt_amd -lazdopt_amd -Wl,-rpath,$PWD/azdopt_amd
   TIMEFORMAT="%R s wall"
-  { for stride in 1 800; do echo "512 agents, 512-1024-512, stride $stride:"; time $O/c21_tree 3 800 512 $stride 0 2>&1 | tail -2; done
-    for stride in 1 800; do echo "4096 agents, 3 x 256, stride $stride:"; time $O/c21_tree 3 800 4096 $stride 0 256 256 256 2>&1 | tail -2; done; } > $O/examples.txt 2>&1
+  { for stride in 1 800; do echo "512 agents, 512-1024-512, stride $stride:"; time $O/c21_tree 3 800 512 $stride 0 2>&1 | tail -1; done
+    for stride in 1 800; do echo "4096 agents, 3 x 256, stride $stride:"; time $O/c21_tree 3 800 4096 $stride 0 256 256 256 2>&1 | tail -1; done; } > $O/examples.txt 2>&1
   echo examples done
 fi
 echo all done
