@@ -39,6 +39,8 @@ for (M, N, K) in shapes:
     g = torch.Generator(device=dev).manual_seed(M + N + K)
     a = (torch.rand(M, K, device=dev, generator=g) * 2 - 1)
     w = (torch.rand(N, K, device=dev, generator=g) * 2 - 1) / K ** 0.5
+    if os.environ.get("AZD_GEMM_ZEROS"):  # zero-filled operands read higher (less switching power: the guide's methodology note); for comparison only
+        a, w = a * 0, w * 0
     bias = torch.rand(N, device=dev, generator=g) - 0.5
     for out_bf16, act in ((False, 2), (True, 1)):
         y, ms, a16, w16 = run(M, N, K, a, w, bias, out_bf16, act, 20)
