@@ -704,6 +704,12 @@ int azd_engine_create(azd_engine **out, const azd_engine_config *cfg, azd_evalua
     a.arc_cap = cfg->arc_capacity > 0 ? (uint32_t)cfg->arc_capacity : 8192u;
     a.pred_cap = cfg->prediction_capacity > 0 ? (uint32_t)cfg->prediction_capacity : 32768u;
     a.ht_cap = (uint32_t)next_pow2((int)(2 * a.node_cap));
+    // what a prediction record packs (engine_types.h: PredRec): child node 16 bits, arc id 16, child's first prediction 20, action id 12
+    if (a.node_cap > 65536u || a.arc_cap > 65535u || a.pred_cap > (1u << 20) || a.A > 4096) {
+        azd::g_last_error = "tree capacities beyond the record format: node_capacity <= 65536, arc_capacity <= 65535, prediction_capacity <= 1048576, ACTION_DIM <= 4096";
+        delete e;
+        return AZD_ERR_INVALID_ARGUMENT;
+    }
     const size_t B = (size_t)a.B;
 #define TRY(x)              \
     do {                    \
@@ -725,6 +731,7 @@ int azd_engine_create(azd_engine **out, const azd_engine_config *cfg, azd_evalua
     TRY(e->alloc(&a.keys, B * a.node_cap * a.KW));
     TRY(e->alloc(&a.arcs, B * a.arc_cap));
     TRY(e->alloc(&a.preds, B * a.pred_cap));
+    TRY(e->alloc(&a.pred_g, B * a.pred_cap));
     TRY(e->alloc(&a.ht, B * a.ht_cap));
     TRY(e->alloc(&a.root_parents, B * azd::PARENTS_STRIDE));
     TRY(e->alloc(&a.cur_parents, B * azd::PARENTS_STRIDE));
@@ -2155,6 +2162,8 @@ int azd_engine_export_tree(azd_engine *e, int agent, float *c, float *c_star, ui
     AZD_HIP(hipMemcpy(nodes.data(), a.nodes + (size_t)agent * a.node_cap, nodes.size() * sizeof(azd::NodeRec), hipMemcpyDeviceToHost));
     if (na) AZD_HIP(hipMemcpy(arcs.data(), a.arcs + (size_t)agent * a.arc_cap, arcs.size() * sizeof(azd::ArcRec), hipMemcpyDeviceToHost));
     if (np) AZD_HIP(hipMemcpy(preds.data(), a.preds + (size_t)agent * a.pred_cap, preds.size() * sizeof(azd::PredRec), hipMemcpyDeviceToHost));
+    std::vector<float> g_exp((size_t)np); // g of the expanded predictions (the record holds the child's summary in its place)
+    if (np) AZD_HIP(hipMemcpy(g_exp.data(), a.pred_g + (size_t)agent * a.pred_cap, g_exp.size() * 4, hipMemcpyDeviceToHost));
     if (keys && a.space == azd::SPACE_DENSE) { // device keys are sets of RANKS: back to action-id sets (kw_host words per node)
         const int KW = a.KW, MAXS = e->dense_slots;
         std::vector<uint64_t> rk((size_t)nn * KW);
@@ -2169,8 +2178,8 @@ int azd_engine_export_tree(azd_engine *e, int agent, float *c, float *c_star, ui
     for (int i = 0; i < nn; ++i) {
         if (c) c[i] = nodes[(size_t)i].c;
         if (c_star) c_star[i] = nodes[(size_t)i].c_star;
-        if (n_t) n_t[i] = nodes[(size_t)i].n_t;
-        if (exhausted) exhausted[i] = nodes[(size_t)i].exhausted;
+        if (n_t) n_t[i] = azd::node_nt(nodes[(size_t)i]);
+        if (exhausted) exhausted[i] = azd::node_exhausted(nodes[(size_t)i]);
         if (act_begin) act_begin[i] = nodes[(size_t)i].act_begin;
         if (act_end) act_end[i] = nodes[(size_t)i].act_end;
     }
@@ -2180,9 +2189,16 @@ int azd_engine_export_tree(azd_engine *e, int agent, float *c, float *c_star, ui
         if (arc_pp) arc_pp[i] = arcs[(size_t)i].pp;
     }
     for (int i = 0; i < np; ++i) {
-        if (pred_a_id) pred_a_id[i] = preds[(size_t)i].a_id;
-        if (pred_g) pred_g[i] = preds[(size_t)i].g;
-        if (pred_arc) pred_arc[i] = preds[(size_t)i].arc == azd::NONE ? -1 : (int32_t)preds[(size_t)i].arc;
+        const azd::PredRec &pr = preds[(size_t)i];
+        const bool ex = azd::pred_expanded(pr);
+        if (pred_a_id) pred_a_id[i] = azd::pred_aid(pr);
+        if (pred_g) {
+            const uint32_t gb = pr.w1;
+            float gv;
+            memcpy(&gv, &gb, 4);
+            pred_g[i] = ex ? g_exp[(size_t)i] : gv;
+        }
+        if (pred_arc) pred_arc[i] = ex ? (int32_t)azd::pred_arc(pr) : -1;
     }
     return AZD_OK;
 }

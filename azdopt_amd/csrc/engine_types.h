@@ -29,15 +29,18 @@ constexpr int PATH_STACK = 32;               // nodes of the current path kept p
 constexpr int MAX_TOL = 32;
 constexpr int NUM_COUNTERS = 32; // 0..15 public counters, 16..24 phase ticks (AZD_PHASE_PROFILE builds), 25..27 evaluator service
 
+// (round 4) The two words a cascade rewrites -- c_star and (n_t, exhausted) -- open the record: one 8-byte store.  n_t counts
+// the cascades that passed through the node, at most one per arc ever added to the tree, so it is bounded by arc_cap
+// (<= 65535: engine limit); exhausted <= the node's action count (<= 2047).
 struct __attribute__((aligned(16))) NodeRec {
-    float c;            // evaluate(cost(state))
     float c_star;       // best eval seen at or below
-    uint32_t n_t;
-    uint32_t exhausted; // exhausted_children
+    uint32_t nt_ex;     // n_t (bits 0-19) | exhausted_children (bits 20-31)
+    float c;            // evaluate(cost(state))
     uint32_t act_begin; // actions: Range<u32> into preds
     uint32_t act_end;
     uint32_t first_in;  // head of the list of LATER arcs into this node (transpositions), NONE if empty
-    uint32_t in_src;    // source of the arc that created the node (NONE for the root)
+    uint32_t in_src;    // source of the arc that created the node (NONE for the root) ...
+    uint32_t in_pp;     // ... and the prediction (index into the tree's preds) that arc expands: where the PARENT keeps this node's summary
 };
 static_assert(sizeof(NodeRec) == 32, "NodeRec must be 32 B");
 
@@ -48,13 +51,41 @@ struct __attribute__((aligned(16))) ArcRec {
 };
 static_assert(sizeof(ArcRec) == 16, "ArcRec must be 16 B");
 
+// (round 4) A prediction carries what next_action needs to know about the CHILD it leads to, so that a selection level is one
+// round trip (the node's predictions) instead of two (the predictions, then a gather of the children's records):
+//   unexpanded   w0 = c_theta_star = c - g as f32 (max_curiosity's candidate value, next_action.rs:63-66; c is the node's own
+//                cost, fixed when the predictions are written), w1 = g, w2 = NONE, w3 = a_id
+//   expanded     w0 = the child's c_star, w1 = the child's n_t (bits 0-19) | its action count (20-30) | active (31),
+//                w2 = child node (bits 0-15) | arc id (16-31), w3 = a_id (bits 0-11) | the child's act_begin (12-31)
+// w0 / w1 of an expanded prediction are rewritten (one 8-byte store) by whoever changes the child: the cascade
+// (empty_transitions.rs:50-127) and the child's add_actions.  g of an expanded prediction moves to Arenas::pred_g (the search
+// never reads it again; the tree export does).  Limits (engine.hip checks them): node_cap <= 65536, arc_cap <= 65535,
+// pred_cap <= 2^20, ACTION_DIM <= 4096, <= 2047 actions per node.
 struct __attribute__((aligned(16))) PredRec {
-    uint32_t a_id;
-    float g;        // g_theta_sa
-    uint32_t arc;   // edge_id: Option<EdgeIndex>, NONE while unexpanded
-    uint32_t child; // target node of `arc` (saves the arcs[] hop during selection)
+    uint32_t w0, w1, w2, w3;
 };
 static_assert(sizeof(PredRec) == 16, "PredRec must be 16 B");
+#if defined(__HIPCC__) || defined(__CUDACC__)
+#define AZD_HD __host__ __device__ inline
+#else
+#define AZD_HD inline
+#endif
+AZD_HD uint32_t node_nt(const NodeRec &r) { return r.nt_ex & 0xFFFFFu; }
+AZD_HD uint32_t node_exhausted(const NodeRec &r) { return r.nt_ex >> 20; }
+AZD_HD uint32_t node_pack(uint32_t n_t, uint32_t exhausted) { return n_t | (exhausted << 20); }
+AZD_HD bool pred_expanded(const PredRec &p) { return p.w2 != NONE; }
+AZD_HD uint32_t pred_aid(const PredRec &p) { return p.w3 & 0xFFFu; }
+AZD_HD uint32_t pred_child(const PredRec &p) { return p.w2 & 0xFFFFu; }
+AZD_HD uint32_t pred_arc(const PredRec &p) { return p.w2 >> 16; }
+AZD_HD uint32_t pred_child_nt(const PredRec &p) { return p.w1 & 0xFFFFFu; }
+AZD_HD uint32_t pred_child_count(const PredRec &p) { return (p.w1 >> 20) & 0x7FFu; }
+AZD_HD bool pred_child_active(const PredRec &p) { return (p.w1 >> 31) != 0u; }
+AZD_HD uint32_t pred_child_begin(const PredRec &p) { return p.w3 >> 12; }
+// the summary words of node r as its parents' predictions keep them
+AZD_HD uint32_t summary_w1(const NodeRec &r) {
+    const uint32_t cnt = r.act_end - r.act_begin;
+    return node_nt(r) | (cnt << 20) | (node_exhausted(r) < cnt ? 0x80000000u : 0u);
+}
 
 // flags[agent] bits
 enum : uint32_t {
@@ -114,6 +145,7 @@ struct Arenas {
     uint64_t *keys;
     ArcRec *arcs;
     PredRec *preds;
+    float *pred_g;          // [B][pred_cap] g_theta_sa of the EXPANDED predictions (PredRec: w1 holds it until then); written once, read by the export only
     uint32_t *ht;
     uint32_t node_cap, arc_cap, pred_cap, ht_cap; // ht_cap is a power of two >= 128
     // per agent
