@@ -151,6 +151,7 @@ def lib():
     sig("azd_engine_observe_dev", C.c_int, vp, C.c_uint32, C.POINTER(vp), C.POINTER(vp), C.POINTER(vp))
     sig("azd_engine_read_state_vecs", C.c_int, vp, vp)
     sig("azd_engine_read_predictions", C.c_int, vp, vp)
+    sig("azd_engine_debug_tile_forward", C.c_int, vp, vp, vp, C.c_int)
     sig("azd_engine_tree_sizes", C.c_int, vp, C.c_int, i32p, i32p, i32p)
     sig("azd_engine_export_tree", C.c_int, vp, C.c_int, *([vp] * 13))
     sig("azd_engine_agent_state", C.c_int, vp, C.c_int, vp, vp, vp, C.POINTER(C.c_uint32), C.POINTER(C.c_double), i32p)

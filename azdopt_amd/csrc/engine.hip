@@ -2126,6 +2126,31 @@ int azd_engine_read_state_vecs(azd_engine *e, float *out) {
     AZD_HIP(hipMemcpy(out, e->a.state_vecs, (size_t)e->a.B * e->a.S * 4, hipMemcpyDeviceToHost));
     return AZD_OK;
 }
+// Test entry: rows of the evaluator as the CU-resident step forms compute them (mlp_tile_task; k_tile_forward), for `rows` state
+// vectors given by the host.  Needs an MLP evaluator the pool step can serve (the plan lays the rows out in LDS).
+int azd_engine_debug_tile_forward(azd_engine *e, const float *states, float *predictions, int rows) {
+    if (!e || !states || !predictions || rows < 1) return AZD_ERR_INVALID_ARGUMENT;
+    AZD_ENTER(e);
+    azd::FusedEval fe;
+    azd::PoolArgs pool = e->pool;
+    uint32_t dyn_stride = 0;
+    size_t dyn_bytes = 0;
+    const char *why = "";
+    if (e->a.space != azd::SPACE_C21 || !e->ev->fused_desc(&fe) || fe.kind != 3 || !azd::pool_plan(e->a, fe, &pool, &dyn_stride, &dyn_bytes, &why)) {
+        azd::g_last_error = "debug_tile_forward: needs the c21 space with an MLP evaluator the pool step can serve";
+        return AZD_ERR_INVALID_ARGUMENT;
+    }
+    float *d_in = nullptr, *d_out = nullptr;
+    AZD_HIP(hipMalloc(&d_in, (size_t)rows * e->a.S * 4));
+    AZD_HIP(hipMalloc(&d_out, (size_t)rows * e->a.A * 4));
+    AZD_HIP(hipMemcpyAsync(d_in, states, (size_t)rows * e->a.S * 4, hipMemcpyHostToDevice, e->stream));
+    azd::launch_tile_forward(fe, pool, rows, d_in, d_out, e->stream);
+    AZD_HIP(hipMemcpyAsync(predictions, d_out, (size_t)rows * e->a.A * 4, hipMemcpyDeviceToHost, e->stream));
+    AZD_HIP(hipStreamSynchronize(e->stream));
+    (void)hipFree(d_in);
+    (void)hipFree(d_out);
+    return AZD_OK;
+}
 int azd_engine_read_predictions(azd_engine *e, float *out) {
     if (!e || !out) return AZD_ERR_INVALID_ARGUMENT;
     AZD_ENTER(e);

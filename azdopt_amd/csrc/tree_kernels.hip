@@ -63,6 +63,55 @@ void launch_pool(const Arenas &a, const PersistArgs *d_args, const StepLaunch &s
     if (a.space == SPACE_RAMSEY) return ramsey_launch_pool(a, d_args, sl, params, wpk, n_blocks, dyn_stride, dyn_bytes, stream);
     DISPATCH_KW(a, l_pool, a, d_args, sl, params, wpk, n_blocks, dyn_stride, dyn_bytes, (hipStream_t)stream);
 }
+// Test entry (azd_engine_debug_tile_forward): the forward of the IN-KERNEL evaluator -- pool_eval's staging and mlp_tile_task's
+// sums, 16 rows per workgroup -- for rows the host hands over.  A prediction row does not depend on the batch it travels in
+// (every output element is its own chain of sums), so these are the rows k_pool's evaluator workgroups hand their agents: the
+// oracle is fed with them, call by call, to check a whole launch of the PRODUCT kernel k_pool<SP, 0> with the real model
+// (tests/test_gpu_pool.py).  f32 or bf16 storage, as the engine's evaluator has it.
+__global__ __launch_bounds__(PERSIST_WAVES * 64) void k_tile_forward(const FusedEval ev, const float *__restrict__ params, const void *__restrict__ wpk,
+                                                                     const uint32_t stride, const uint32_t out_off, const int n_rows,
+                                                                     const float *__restrict__ states, float *__restrict__ out) {
+    __shared__ uint32_t agents[PERSIST_WAVES];
+    const int tid = threadIdx.x, wave = tid >> 6, first = blockIdx.x * PERSIST_WAVES;
+    const int n = n_rows - first < PERSIST_WAVES ? n_rows - first : PERSIST_WAVES;
+    const int S = ev.dims[0], S16 = (S + 15) & ~15, L = ev.n_layers, A = ev.dims[L];
+    if (tid < PERSIST_WAVES) agents[tid] = (uint32_t)(first + tid);
+    PoolRows rows;
+    rows.stride = stride;
+    rows.out_off = out_off;
+    rows.agents = agents;
+    rows.n = n;
+    EvalPtrs gp;
+    gp.params = params;
+    gp.wpk = wpk;
+    gp.state_vecs = states;
+    gp.h_theta = out;
+    for (int idx = tid; idx < n * S16; idx += PERSIST_WAVES * 64) {
+        const int r = idx / S16, c = idx - r * S16;
+        const float v = c < S ? states[(size_t)(first + r) * S + c] : 0.f;
+        if (ev.bf16) reinterpret_cast<uint16_t *>(rows.row(r))[c] = (uint16_t)bf16_bits(v);
+        else rows.row(r)[c] = v;
+    }
+    __syncthreads();
+    for (int l = 0; l < L; ++l) {
+        const int nt = (ev.dims[l + 1] + 15) >> 4;
+        for (int tile = wave; tile < nt; tile += PERSIST_WAVES) {
+            unsigned long long ph[3];
+            mlp_tile_task<PoolRows, true>(ev, rows, gp, l, tile, ph);
+        }
+        __syncthreads();
+    }
+    for (int idx = tid; idx < n * A; idx += PERSIST_WAVES * 64) {
+        const int r = idx / A, c = idx - r * A;
+        out[(size_t)(first + r) * A + c] = rows.out(r)[c];
+    }
+}
+void launch_tile_forward(const FusedEval &ev, const PoolArgs &pool, int n_rows, const float *states, float *out, void *stream) {
+    const size_t dyn_bytes = (size_t)pool.eval_stride * sizeof(float) * PERSIST_WAVES;
+    if (hipFuncSetAttribute((const void *)k_tile_forward, hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn_bytes) != hipSuccess) return;
+    k_tile_forward<<<dim3((n_rows + PERSIST_WAVES - 1) / PERSIST_WAVES), dim3(PERSIST_WAVES * 64), dyn_bytes, (hipStream_t)stream>>>(
+        ev, ev.params, ev.wpk, pool.eval_stride, pool.eval_out_off, n_rows, states, out);
+}
 template <class SP>
 static void q_pool_resident(int *out, size_t dyn_bytes) {
     int nb = 0;

@@ -242,6 +242,14 @@ class NablaOptimizer:
         _lib.check(self._L.azd_engine_read_predictions(self._h, _lib.ptr(h)), "read_predictions")
         return h
 
+    def debug_tile_forward(self, states):
+        """Test entry: prediction rows exactly as the CU-resident step forms' in-kernel evaluator computes them, for the given
+        state vectors [rows, STATE_DIM] (a checker's: tests/test_gpu_pool.py follows a launch of the product kernel with them)."""
+        st = np.ascontiguousarray(states, np.float32).reshape(-1, self.space.STATE_DIM)
+        out = np.zeros((st.shape[0], self.space.ACTION_DIM), np.float32)
+        _lib.check(self._L.azd_engine_debug_tile_forward(self._h, _lib.ptr(st), _lib.ptr(out), st.shape[0]), "debug_tile_forward")
+        return out
+
     # ---- introspection
     def tree_sizes(self, agent):
         a, b, c = C.c_int32(), C.c_int32(), C.c_int32()

@@ -381,12 +381,14 @@ def main():
         # it.  Bound: resident searching waves / (dependent round trips per call x the idle HBM-miss latency of
         # MI355X_MICROARCH.md, ~900 cycles = 375 ns).  What separates `achieved` from it: queueing behind the other waves'
         # misses on the CU's in-order memory path, and the arithmetic between the loads (lambda_1).
-        # Per call with a new node: two round trips per selection level (the pool step takes the first level's choice from
-        # add_actions' registers), two per table probe, two per cascade (the path's records in one gather, then the arcs of a
-        # node with several parents), six for the hand-overs (state in, row / request out, queue words).
+        # Per call with a new node (round 4: a prediction carries its child's summary, PredRec): ONE round trip per selection
+        # level -- the node's predictions; the pool step takes the first level's choice from add_actions' registers -- plus the
+        # node's own record at the top of every descent from the root (after a terminal or a transposition), two per table
+        # probe (slot, then key), two per cascade (the path's records and the node met in one gather, then the arcs of a node
+        # with several parents), six for the hand-overs (state in, row / request out, queue words).
         sel = d["SELECT_CALLS"] - (d["EXPANSIONS"] if (form == "pool" and wl["kind"] != "dense") else 0)
         events = d["TERMINALS"] + d["TRANSPOSITIONS"]
-        chain = (2 * sel + 2 * (d["EXPANSIONS"] + events) + 2 * events) / max(1, d["EXPANSIONS"]) + 6
+        chain = (sel + events + 2 * (d["EXPANSIONS"] + events) + 2 * events) / max(1, d["EXPANSIONS"]) + 6
         waves = opt.pool_split()[1] * 16 if form == "pool" else min(B, 4096)
         lat_peak = waves / (chain * 0.375e-6)
         lat_rate = exp_for_roofline / launches / (avg_ms * 1e-3) if avg_ms > 0 else 0.0

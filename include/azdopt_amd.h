@@ -388,6 +388,10 @@ int azd_engine_observe_dev(azd_engine *e, uint32_t n_obs_tol, const float **d_st
                            const float **d_observations, const float **d_action_weights);
 int azd_engine_read_state_vecs(azd_engine *e, float *state_vecs); /* batch*state_dim */
 int azd_engine_read_predictions(azd_engine *e, float *h_theta);   /* last h_theta, batch*action_dim */
+/* Test entry: `rows` prediction rows exactly as the CU-resident step forms' in-kernel evaluator computes them (the same sums in
+ * the same order; the model call of model/dfdx.rs:69-84), for state vectors the host hands over: what a checker feeds its
+ * restatement with to follow a whole launch of the product kernel with the real model.  c21 space, MLP evaluator. */
+int azd_engine_debug_tile_forward(azd_engine *e, const float *states, float *predictions, int rows);
 
 /* Introspection (SearchTree::{nodes, positions, node_data}, tree/mod.rs:302-315;
  * get_trees, optimizer/mod.rs:34-36): raw arrays instead of graphviz. */

@@ -116,6 +116,47 @@ def test_dense_pool_step_against_the_oracle(az, orc, n, B, p, kmin, kmax, tol, s
     assert c["EXPANSIONS"] > 100
 
 
+def test_dense_pool_step_with_more_agents_than_waves_against_the_oracle(az, orc, monkeypatch):
+    """four searcher workgroups (64 waves) for 300 agents: every agent queues for a wave and changes waves and CUs many times --
+    the product regime of config E (8192 agents on 2048 waves) -- against the oracle, with the device root policy and a second epoch"""
+    monkeypatch.setenv("AZD_DENSE_POOL_SEARCH_WGS", "4")
+    c = run_dense_parity(az, orc, 20, 300, 0.2, 5, 60, ([50, 20, 10], 5), steps=120, epochs=2, seed=11, check_every=60, policy=True, pool=True)
+    assert c["EXPANSIONS"] > 20000
+
+
+def test_dense_pool_step_at_config_e_population_against_the_oracle(az, orc):
+    """N = 50, 4096 agents (twice the searching waves), 100 calls per launch, device root policy, a second epoch: counters, state
+    vectors, argmin, the new roots and a sample of the trees against the oracle"""
+    n, B, p, kmin, kmax, seed, calls = 50, 4096, 0.1, 5, 128, 3, 100
+    tol = ([200, 50, 50], 25)
+    space = az.DenseGraphSpace(n, p, max_slots=128)
+    model = az.HashStreamModel(space.STATE_DIM, space.ACTION_DIM, seed).serve_from_pool_evaluators()
+    roots = space.generate_roots(seed, B, kmin=kmin, kmax=kmax)
+    opt = az.NablaOptimizer.par_new(space, roots, model, B, pool_step=True)
+    oe = orc.Engine(n, B, threads=16, dense=True, dense_p=p)
+    oe.new_begin(*roots)
+    call = 0
+    oe.new_end(orc.hash_predictions(seed, 0, B, space.ACTION_DIM, call))
+    for epoch in range(2):
+        ig = opt.par_roll_out_episodes(tol, n_calls=calls)
+        assert opt.step_form() == ("pool", "")
+        io = 0
+        for _ in range(calls):
+            oe.rollout_begin(*tol)
+            call += 1
+            io += oe.rollout_end(orc.hash_predictions(seed, 0, B, space.ACTION_DIM, call))
+        assert ig == io
+        assert opt.pool_split()[1] * 16 < B  # fewer searching waves than agents
+        compare(opt, oe, range(0, B, 97), f"epoch {epoch}")
+        new_roots = oe.modify_roots(seed, epoch, 0, kmin, kmax)
+        got = opt.modify_roots(seed, epoch, kmin, kmax)
+        assert np.array_equal(got[0], new_roots[0]) and np.array_equal(got[1], new_roots[1]), epoch
+        opt.par_reset_trees_policy(seed, epoch, kmin, kmax)
+        oe.reset_begin(*new_roots)
+        call += 1
+        oe.reset_end(orc.hash_predictions(seed, 0, B, space.ACTION_DIM, call))
+
+
 @pytest.mark.parametrize("B,max_slots,kmax", [(640, 128, 128), (256, 612, 612)])
 def test_dense_pool_step_with_the_bf16_model_equals_the_launch_per_phase_form(az, monkeypatch, B, max_slots, kmax):
     """config E's model on the pool step: the rows the searchers post are gathered into the batched bf16 GEMMs (k_gemm16 with row

@@ -304,6 +304,49 @@ def test_pool_whole_epochs_against_the_oracle(az, orc, B, early_post, monkeypatc
     _check_against_snapshot(opt, imp, snaps[1], "epoch 1")
 
 
+def test_product_pool_kernel_with_the_real_model_over_whole_epochs_against_the_oracle(az, orc):
+    """The PRODUCT kernel k_pool<SP, 0> (no harness bit) with the real 3 x 256 model, 800 calls in one launch at 256 agents, the
+    optimiser step and the device root policy, 800 more -- against the oracle.  The oracle cannot compute the model's rows to
+    the bit, so it is fed, call by call, with the rows of ITS OWN state vectors as the in-kernel evaluator computes them
+    (debug_tile_forward: pool_eval's staging and mlp_tile_task's sums; a row does not depend on the batch it travels in).
+    If the launch's trees equal the oracle's at the end, every row and every state along the way did."""
+    n, B, seed, calls, n_obs_tol = 19, 256, 31, 800, 200
+    space = az.ROTModifyParentsOnce(n)
+    kmin, kmax = space.default_permitted_range()
+    roots = space.generate_roots(seed, B)
+    model = az.ActionModel(B, space.STATE_DIM, space.ACTION_DIM, hidden=(256, 256, 256), seed=seed)
+    opt = az.NablaOptimizer.par_new(space, roots, model, B, pool_step=True)
+    oe = orc.Engine(n, B, threads=8)
+    oe.new_begin(*roots)
+    oe.new_end(opt.predictions())  # (the roots' rows come from the model call of par_new: the batched forward)
+    for epoch in range(2):
+        io = 0
+        for _ in range(calls):
+            oe.rollout_begin(*TOL_REF)
+            io += oe.rollout_end(opt.debug_tile_forward(oe.state_vecs()))
+        ig = opt.par_roll_out_episodes(TOL_REF, n_calls=calls)  # ONE launch of the product kernel
+        assert opt.step_form() == ("pool", "")
+        assert ig == io, epoch
+        cg, co = opt.counters(), oe.counters()
+        for k in MAIN_CTRS:
+            assert cg[k] == co[k], (epoch, k, cg[k], co[k])
+        assert cg["EVAL_ROWS"] == cg["EXPANSIONS"] > 100 * B
+        assert np.array_equal(opt.state_vecs(), oe.state_vecs()), epoch
+        for i in range(B):
+            assert_tree_equal(opt.get_tree(i), oe.export_tree(i), f"epoch {epoch} agent {i}")
+        ag, ao = opt.argmin_data(), oe.argmin()
+        assert ag.eval == ao["eval"] and np.array_equal(ag.state["parents"], ao["parents"]), epoch
+        if epoch == 0:
+            sv, obs, w = opt.observe(n_obs_tol)
+            oo, ow = oe.observe(n_obs_tol)
+            assert np.array_equal(obs.view(np.uint32), oo.view(np.uint32)) and np.array_equal(w, ow)
+            assert np.isfinite(opt.par_update_model(n_obs_tol))  # Adam step on the device: the second epoch runs on new weights
+            new_roots = oe.modify_roots(seed, 0, 0, kmin, kmax)
+            opt.par_reset_trees_policy(seed, 0)
+            oe.reset_begin(*new_roots)
+            oe.reset_end(opt.predictions())
+
+
 @pytest.mark.parametrize("model_kind", ["hash", "mlp"])
 def test_pool_abort_is_taken_over_by_the_async_step(az, orc, model_kind, monkeypatch):
     """PoolCtl::abort (a wait ran into its bound) no longer fails the call: the asynchronous step takes the launch over
