@@ -158,6 +158,39 @@ def cpu_baseline(n_threads, wl, hidden, krange, budget_s=24.0):
                 tree_only=rows["tree_only"], end_to_end=rows["end_to_end"])
 
 
+def best_cost_run(az, wl, hidden, B, mlp_dtype, max_epochs, goal=5.2):
+    """The other half of the metric (BASELINE.json: best-cost-found), outside the timed region: the reference driver's loop
+    (graph-state/examples/04-c21-tree.rs:133-208 -- 800 episodes, one optimiser step with Adam lr 1e-4 / L2 1e-6, the root
+    policy) on a fresh engine until lambda_1 + mu < 5.2 (:117,125) or max_epochs; then the same loop with the model never
+    updated, for as many epochs (control: what the search and the root policy find without learning).  Trajectories over 250
+    epochs, a CPU-restatement arm and an lr x 100 arm: profiles/r04_best_cost.txt (tools/best_cost.py)."""
+    space = az.ROTModifyParentsOnce(wl["n"])
+    kmin, kmax = space.default_permitted_range()
+    out = {"goal": goal, "max_epochs": max_epochs, "episodes_per_epoch": 800}
+    t0 = time.perf_counter()
+    epochs_trained = max_epochs
+    for arm in ("trained", "frozen_control"):
+        model = az.ActionModel(B, space.STATE_DIM, space.ACTION_DIM, hidden=hidden, lr=1e-4, betas=(0.9, 0.999), eps=1e-8, l2=1e-6, seed=SEED, dtype=mlp_dtype)
+        opt = az.NablaOptimizer.par_new(space, space.generate_roots(SEED, B, kmin=kmin, kmax=kmax), model, B, **wl["caps"])
+        best, first, ep = None, None, 0
+        for ep in range(1, (max_epochs if arm == "trained" else epochs_trained) + 1):
+            opt.par_roll_out_episodes(wl["tol"], n_calls=800)
+            am = opt.argmin_data()
+            best = len(am.cost["matching"]) + am.cost["lambda_1"]
+            first = best if first is None else first
+            if best < goal:
+                break
+            if arm == "trained":
+                opt.par_update_model(200)
+            opt.par_reset_trees_policy(SEED, ep, kmin, kmax)
+        if arm == "trained":
+            epochs_trained = ep
+        out[arm] = {"epochs": ep, "best_cost": best, "best_cost_after_first_epoch": first, "reached_goal": bool(best < goal)}
+        del opt, model
+    out["seconds"] = time.perf_counter() - t0
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -165,6 +198,9 @@ def main():
     ap.add_argument("--warmup", type=int, default=800)
     ap.add_argument("--cpu-seconds", type=float, default=24.0, help="CPU time budget of the cpu_baseline leg")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--best-cost-epochs", type=int, default=120,
+                    help="c21 workloads at N = 1: after the timed region, run the reference driver's loop for at most this many epochs "
+                         "(until lambda_1 + mu < 5.2) and a frozen-model control beside it (0: skip)")
     ap.add_argument("--chunk", type=int, default=800, help="calls per host round trip (<= one epoch)")
     ap.add_argument("--barrier-step", action="store_true", help="lock-step form (k_persist) instead of the default asynchronous step (k_async)")
     ap.add_argument("--step", choices=["async", "barrier", "pool"], default=None,
@@ -455,6 +491,8 @@ def main():
                                      "frac": ach / (chip_peak * cus / 256.0) if cus else None, "cus": cus, "flop_per_row": flop_per_row,
                                      "note": "rows served per second x the model's flop per row, against the dense matrix-core peak of the CUs "
                                              "the evaluator side holds (%s storage)" % ("fp32" if mlp_dtype == "f32" else "bf16")}
+        out["best_cost_run"] = (best_cost_run(az, wl, HIDDEN, AGENTS_PER_GPU, mlp_dtype, args.best_cost_epochs)
+                                if (world == 1 and wl["kind"] == "c21" and mlp_dtype and args.best_cost_epochs > 0 and not args.no_cpu_baseline) else None)
         if not args.no_cpu_baseline and world == 1:  # timed beside the GPU run at N = 1 only
             out["cpu_baseline"] = cpu_baseline(min(os.cpu_count() or 1, 64), wl, HIDDEN, space.default_permitted_range(), args.cpu_seconds)
         else:
