@@ -247,3 +247,35 @@ def test_ramsey_epoch_is_reproducible_at_full_size(az, dtype):
                     assert np.array_equal(xn, yn), (i, f)
                     x, y = np.where(xn, 0, x), np.where(yn, 0, y)
                 assert x.shape == y.shape and np.array_equal(x, y), (i, f)
+
+
+def test_ramsey_pool_abort_taken_over_by_k_async_with_a_resume_table_against_the_oracle(az, orc, monkeypatch):
+    """Regression for the round-3 fault (HSA_STATUS_ERROR_MEMORY_APERTURE_VIOLATION in k_async<RamseySpace<5>>, the build in which
+    hipcc had left rollout_agent out of line: DESIGN.md "Two faults, one cause"): r44 (five key words) on the pool step with a
+    forced abort, so that k_async<RamseySpace<5>> runs with a NON-NULL resume table -- agents through all calls, agents whose
+    row is still due, agents never taken -- and the result is the oracle's."""
+    n, sizes, weights, B, seed, calls = 17, [4, 4], [1.0, 1.0], 300, 13, 50
+    tol = ([200, 200, 100, 100, 50, 50, 25, 25], 10)
+    space = az.RamseySpaceNoEdgeRecolor(n, sizes, weights)
+    assert space.KEY_WORDS == 5
+    roots = space.generate_roots(seed, B)
+    monkeypatch.setenv("AZD_POOL_DEBUG_ABORT_CALL", "5")
+    model = az.HashStreamModel(space.STATE_DIM, space.ACTION_DIM, seed).serve_from_pool_evaluators()
+    opt = az.NablaOptimizer.par_new(space, roots, model, B, pool_step=True, prediction_capacity=131072)
+    imp = opt.par_roll_out_episodes(tol, n_calls=calls)
+    form, why = opt.step_form()
+    assert form == "async" and why.startswith("pool step aborted"), (form, why)
+    oe = orc.Engine(n, B, threads=8, ramsey=(sizes, weights))
+    oe.new_begin(*roots)
+    oe.new_end(orc.hash_predictions(seed, 0, B, space.ACTION_DIM, 0))
+    io = 0
+    for call in range(1, calls + 1):
+        oe.rollout_begin(*tol)
+        io += oe.rollout_end(orc.hash_predictions(seed, 0, B, space.ACTION_DIM, call))
+    assert imp == io
+    cg, co = opt.counters(), oe.counters()
+    for k in MAIN_CTRS:
+        assert cg[k] == co[k], (k, cg[k], co[k])
+    assert np.array_equal(opt.state_vecs(), oe.state_vecs())
+    for i in range(0, B, 3):
+        assert_tree_equal(opt.get_tree(i), oe.export_tree(i), f"agent {i}")
