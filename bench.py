@@ -405,11 +405,18 @@ def main():
             try:
                 tj = json.load(open(tpath))
                 # FETCH_SIZE as counted (one 64-B request per missed record: profiles/r02_gather_calib.txt) + WRITE_SIZE
-                per_call = tj["k_pool_hbm_bytes_per_call"] if form == "pool" else tj["k_async"]["hbm_bytes_per_call_raw"]
-                traffic = per_call * args.steps / launches
-                traffic_src = "profiles/traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE of %s in separate passes over 800-call launches, " \
-                              "calibrated for record gathers by profiles/r02_gather_calib.txt) x %.0f calls per launch; not measured in this run" \
-                              % (kernel, args.steps / launches)
+                cpl = args.steps / launches
+                d20 = tj.get("k_pool_driver20")
+                if form == "pool" and d20 and abs(cpl - d20["calls_per_launch"]) < 0.5:  # the driver's window: a profile of launches of this very shape
+                    traffic = d20["hbm_bytes_per_call"] * cpl
+                    traffic_src = "profiles/traffic.json k_pool_driver20 (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE of %s in separate passes over the same " \
+                                  "command: launches of %.0f calls, the timed one; record gathers calibrated by profiles/r02_gather_calib.txt); not measured in this run" % (kernel, cpl)
+                else:
+                    per_call = tj["k_pool_hbm_bytes_per_call"] if form == "pool" else tj["k_async"]["hbm_bytes_per_call_raw"]
+                    traffic = per_call * cpl
+                    traffic_src = "profiles/traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE of %s in separate passes over 800-call launches, " \
+                                  "calibrated for record gathers by profiles/r02_gather_calib.txt) x %.0f calls per launch; not measured in this run" \
+                                  % (kernel, cpl)
             except Exception:
                 traffic = None
         # the limiter the kernel actually runs into: a call is a CHAIN of dependent gathers (a node's predictions, then its

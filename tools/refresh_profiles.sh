@@ -1,9 +1,9 @@
 #!/bin/bash
 # Profile refresh of a round (run on the GPU box through gpurun; tools/update_profiles.py copies the summaries to profiles/):
-#   tools/refresh_profiles.sh r03 [part ...]     parts: bench stats tcc sq gemm split curve examples  (default: all)
+#   tools/refresh_profiles.sh r04 [part ...]     parts: bench stats tcc tcc20 l2 sq gemm split curve examples  (default: all)
 export TMPDIR=/tmp
 R=${1:-r03}; shift
-PARTS=${*:-bench stats tcc sq gemm split curve examples}
+PARTS=${*:-bench stats tcc tcc20 l2 sq gemm split curve examples}
 O=gpurun_out/final_$R
 mkdir -p $O
 has() { [[ " $PARTS " == *" $1 "* ]]; }
@@ -31,6 +31,15 @@ if has tcc; then
   timeout -k 10 300 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $O/pmc_write -- python3 bench.py --no-cpu-baseline > $O/pmc_write.log 2>&1
   echo tcc done
 fi
+if has tcc20; then  # the same two counters over the DRIVER's window: launches of 20 calls (bench.py --steps 20 --warmup 5)
+  timeout -k 10 300 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $O/pmc_fetch20 -- python3 bench.py --no-cpu-baseline --steps 20 --warmup 5 > $O/pmc_fetch20.log 2>&1
+  timeout -k 10 300 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $O/pmc_write20 -- python3 bench.py --no-cpu-baseline --steps 20 --warmup 5 > $O/pmc_write20.log 2>&1
+  echo tcc20 done
+fi
+if has l2; then  # where the tree's records are served from: L2 hits / misses of k_pool (all XCDs summed), one pass
+  timeout -k 10 300 rocprofv3 --pmc TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum --kernel-trace --output-format csv -d $O/pmc_l2 -- python3 bench.py --no-cpu-baseline --steps 800 --warmup 800 > $O/pmc_l2.log 2>&1
+  echo l2 done
+fi
 if has sq; then
   timeout -k 10 300 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_SCA --kernel-trace --output-format csv -d $O/pmc_sq1 -- python3 bench.py --no-cpu-baseline --steps 800 --warmup 800 > $O/pmc_sq1.log 2>&1
   timeout -k 10 300 rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_SMEM SQ_WAVES SQ_INSTS_VALU_MFMA_MOPS_F32 --kernel-trace --output-format csv -d $O/pmc_sq2 -- python3 bench.py --no-cpu-baseline --steps 800 --warmup 800 > $O/pmc_sq2.log 2>&1
@@ -47,8 +56,7 @@ if has split; then
   echo split done
 fi
 if has curve; then
-  { timeout -k 10 300 python tools/launch_curve.py B 1 5 20 800 w1 w5; AZD_LIB=$PWD/azdopt_amd/libazdopt_amd_r02.so timeout -k 10 300 python tools/launch_curve.py B 1 5 20 800
-    timeout -k 10 300 python tools/launch_curve.py A 1 5 20 800 w1; AZD_LIB=$PWD/azdopt_amd/libazdopt_amd_r02.so timeout -k 10 300 python tools/launch_curve.py A 1 5 20 800; } > $O/curve.txt 2>&1
+  { timeout -k 10 300 python tools/launch_curve.py B 1 5 20 800 w1 w5;     timeout -k 10 300 python tools/launch_curve.py A 1 5 20 800 w1; } > $O/curve.txt 2>&1
   echo curve done
 fi
 if has examples; then

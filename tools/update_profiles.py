@@ -8,7 +8,7 @@ import shutil
 import subprocess
 import sys
 
-R = sys.argv[1] if len(sys.argv) > 1 else "r03"
+R = sys.argv[1] if len(sys.argv) > 1 else "r04"
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 O = os.path.join(ROOT, "gpurun_out", "final_" + R)
 P = os.path.join(ROOT, "profiles")
@@ -76,6 +76,47 @@ if ff and fw:
     engine_rows(ff, os.path.join(P, R + "_pool_pmc_fetch_size.csv"))
     engine_rows(fw, os.path.join(P, R + "_pool_pmc_write_size.csv"))
     print("k_pool traffic per call: %.1f MB (FETCH %.1f + WRITE %.1f)" % (raw / 1e6, fetch * 1024 / calls / 1e6, write * 1024 / calls / 1e6))
+# the driver's window: launches of 20 calls (bench.py --steps 20 --warmup 5 runs the timed launch once after an untimed epoch and warm-up launches of the same shape)
+f20, w20 = newest("pmc_fetch20/**/*counter_collection.csv"), newest("pmc_write20/**/*counter_collection.csv")
+if f20 and w20:
+    def launches_of(path, counter):  # per-dispatch totals of k_pool, in dispatch order
+        by = {}
+        for r in csv.DictReader(open(path)):
+            if r["Counter_Name"] == counter and "k_pool" in r["Kernel_Name"]:
+                by[int(r["Dispatch_Id"])] = by.get(int(r["Dispatch_Id"]), 0.0) + float(r["Counter_Value"])
+        return [by[k] for k in sorted(by)]
+    fl, wl_ = launches_of(f20, "FETCH_SIZE"), launches_of(w20, "WRITE_SIZE")
+    # the 20-call launches are the ones with the smallest write totals (an 800-call epoch writes 40 x as much)
+    small_f = sorted(fl)[: max(1, len(fl) // 2)]
+    small_w = sorted(wl_)[: max(1, len(wl_) // 2)]
+    f_last, w_last = fl[-1], wl_[-1]  # the timed launch is the last dispatch of the kernel
+    t = json.load(open(os.path.join(P, "traffic.json")))
+    t["k_pool_driver20"] = {
+        "kernel": "k_pool<3>, launches of 20 calls mid-epoch (the driver's bench.py --steps 20 --warmup 5), 4096 agents; %s" % R,
+        "calls_per_launch": 20, "FETCH_SIZE_KB_timed_launch": f_last, "WRITE_SIZE_KB_timed_launch": w_last,
+        "hbm_bytes_per_call": (f_last + w_last) * 1024 / 20.0,
+        "all_k_pool_dispatches_FETCH_KB": fl, "all_k_pool_dispatches_WRITE_KB": wl_,
+        "commands": ["rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d gpurun_out/final_%s/pmc_fetch20 -- python3 bench.py --no-cpu-baseline --steps 20 --warmup 5" % R,
+                     "rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d gpurun_out/final_%s/pmc_write20 -- python3 bench.py --no-cpu-baseline --steps 20 --warmup 5" % R],
+    }
+    json.dump(t, open(os.path.join(P, "traffic.json"), "w"), indent=1)
+    engine_rows(f20, os.path.join(P, R + "_pool_driver20_pmc_fetch_size.csv"))
+    engine_rows(w20, os.path.join(P, R + "_pool_driver20_pmc_write_size.csv"))
+    print("k_pool traffic per call in the driver's 20-call launch: %.1f MB (FETCH %.1f + WRITE %.1f)" % (
+        (f_last + w_last) * 1024 / 20 / 1e6, f_last * 1024 / 20 / 1e6, w_last * 1024 / 20 / 1e6))
+l2 = newest("pmc_l2/**/*counter_collection.csv")
+if l2:
+    tot = {}
+    for r in csv.DictReader(open(l2)):
+        if "k_pool" in r["Kernel_Name"]:
+            tot[r["Counter_Name"]] = tot.get(r["Counter_Name"], 0.0) + float(r["Counter_Value"])
+    with open(os.path.join(P, R + "_pool_pmc_l2.txt"), "w") as f:
+        f.write("# rocprofv3 --pmc TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum over bench.py --steps 800 --warmup 800 (k_pool<3>, 4096 agents; all XCDs summed, all dispatches)\n")
+        for k in sorted(tot):
+            f.write("%s %.0f\n" % (k, tot[k]))
+        if tot.get("TCC_HIT_sum", 0) + tot.get("TCC_MISS_sum", 0) > 0:
+            f.write("L2 hit rate %.4f\n" % (tot["TCC_HIT_sum"] / (tot["TCC_HIT_sum"] + tot["TCC_MISS_sum"])))
+    print(open(os.path.join(P, R + "_pool_pmc_l2.txt")).read())
 for src, dst in (("prof/**/*kernel_stats.csv", "_pool_kernel_stats.csv"), ("prof20/**/*kernel_stats.csv", "_pool_driver20_kernel_stats.csv"),
                  ("prof_E/**/*kernel_stats.csv", "_configE_kernel_stats.csv")):
     f = newest(src)
