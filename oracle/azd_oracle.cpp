@@ -170,7 +170,7 @@ double lambda1_jacobi(const uint8_t *parents, int n) {
  * every operation a single IEEE f64 multiply / add / subtract (no fused ops).  Ten rounds of
  * 64-way multisection of [1, N] leave hi - lo ~ 1 ulp; lambda_1 := hi, the smallest tested x
  * that is positive definite. */
-inline bool posdef_at(const uint8_t *parents, int n, double x) {
+inline bool posdef_at(const uint8_t *parents, int n, double x, double *phi0_out = nullptr) {
     double P[MAXN], Q[MAXN];
     for (int v = 0; v < n; ++v) {
         P[v] = 1.0;
@@ -190,6 +190,7 @@ inline bool posdef_at(const uint8_t *parents, int n, double x) {
     double xp0 = x * P[0];
     double phi0 = xp0 - Q[0];
     if (!(phi0 > 0.0)) ok = false;
+    if (phi0_out) *phi0_out = phi0; /* the tree's characteristic polynomial at x (round 4: the secant window below) */
     return ok;
 }
 /* 32 trial points per round (33-section of [lo, hi]), at most 12 rounds (33^12 > 2^60).
@@ -204,27 +205,59 @@ void lambda1_bracket(int n, double *lo, double *hi) {
     *lo = (double)(float)(2.0 * std::cos(3.14159265358979323846 / (double)(n + 1))) - 0x1p-20;
     *hi = (double)(float)std::sqrt((double)(n - 1)) + 0x1p-20;
 }
+/* Round 4: once both ends of the bracket carry a value of the tree's characteristic polynomial phi_0 with the signs of a simple
+ * crossing (phi_0(lo) < 0 < phi_0(hi)), the 32 trial points of a round go into a window around the secant's estimate of the root
+ * -- half-width 8 (span / 2)^2, at least span / 1024 -- clipped to the bracket, instead of across the whole bracket.  The ends are
+ * only ever replaced by trial points, so the bracket stays a bracket; 5.25 -> 3.6 rounds per node cost.  The device runs exactly
+ * these operations (space_c21.inc:lambda1_impl), one IEEE f64 operation each. */
 double lambda1_sturm(const uint8_t *parents, int n, bool node_mode) {
     double lo, hi;
     lambda1_bracket(n, &lo, &hi);
+    double flo = 0.0, fhi = 0.0;
+    bool have_lo = false, have_hi = false;
     for (int round = 0; round < 12; ++round) {
         if (node_mode && (float)lo == (float)hi) break;
-        double w = (hi - lo) / 33.0;
+        double wlo = lo, whi = hi;
+        if (have_lo && have_hi && flo < 0.0 && fhi > 0.0) {
+            double span = hi - lo;
+            double den = flo - fhi;
+            double tt = flo / den;
+            double st = span * tt;
+            double c = lo + st;
+            double half = span * 0.5;
+            double hh = half * half;
+            double d = 8.0 * hh;
+            double dmin = span * 0.0009765625;
+            if (d < dmin) d = dmin;
+            if (d < half) {
+                double wa = c - d, wb = c + d;
+                if (wa > lo) wlo = wa;
+                if (wb < hi) whi = wb;
+            }
+        }
+        double ws = whi - wlo;
+        double w = ws / 33.0;
         int first = 32;
-        double xs[32];
+        double xs[32], ph[32];
         for (int j = 0; j < 32; ++j) {
             double step = w * (double)(j + 1);
-            xs[j] = lo + step;
+            xs[j] = wlo + step;
         }
         for (int j = 0; j < 32; ++j)
-            if (posdef_at(parents, n, xs[j])) {
+            if (posdef_at(parents, n, xs[j], &ph[j])) {
                 first = j;
                 break;
             }
-        double nlo = first > 0 ? xs[first - 1] : lo;
-        double nhi = first < 32 ? xs[first] : hi;
-        lo = nlo;
-        hi = nhi;
+        if (first > 0) {
+            lo = xs[first - 1];
+            flo = ph[first - 1];
+            have_lo = true;
+        }
+        if (first < 32) {
+            hi = xs[first];
+            fhi = ph[first];
+            have_hi = true;
+        }
     }
     return hi;
 }

@@ -116,9 +116,10 @@ def posdef(parents, n, x):
         p = parents[v]
         Q[p] = Q[p] * phi + P[p] * P[v]
         P[p] = P[p] * phi
-    if not (x * P[0] - Q[0]) > 0.0:
+    phi0 = x * P[0] - Q[0]
+    if not phi0 > 0.0:
         ok = False
-    return ok
+    return ok, phi0
 
 
 def lambda1(parents, n, node_mode=False):
@@ -128,17 +129,47 @@ def lambda1(parents, n, node_mode=False):
     # largest, sqrt(n - 1); both rounded to f32 and widened by 2^-20 (so that every restatement starts from the same doubles)
     lo = float(F(2.0 * math.cos(math.pi / (n + 1)))) - 2.0 ** -20
     hi = float(F(math.sqrt(float(n - 1)))) + 2.0 ** -20
+    # round 4: with phi_0 (the tree's characteristic polynomial) known at both ends and of the signs of a simple crossing, the
+    # round's trial points go into a window around the secant's estimate of the root (half-width 8 (span / 2)^2, at least
+    # span / 1024, clipped to the bracket); the ends are only ever replaced by trial points, so the bracket stays a bracket
+    flo = fhi = 0.0
+    have_lo = have_hi = False
     for _ in range(12):
         if node_mode and F(lo) == F(hi):
             break
-        w = (hi - lo) / 33.0
-        xs = [lo + w * float(j + 1) for j in range(32)]
+        wlo, whi = lo, hi
+        if have_lo and have_hi and flo < 0.0 and fhi > 0.0:
+            span = hi - lo
+            den = flo - fhi
+            tt = flo / den
+            st = span * tt
+            c = lo + st
+            half = span * 0.5
+            hh = half * half
+            d = 8.0 * hh
+            dmin = span * 0.0009765625
+            if d < dmin:
+                d = dmin
+            if d < half:
+                wa, wb = c - d, c + d
+                if wa > lo:
+                    wlo = wa
+                if wb < hi:
+                    whi = wb
+        ws = whi - wlo
+        w = ws / 33.0
+        xs = [wlo + w * float(j + 1) for j in range(32)]
+        ph = [0.0] * 32
         first = 32
         for j in range(32):
-            if posdef(parents, n, xs[j]):
+            ok, ph[j] = posdef(parents, n, xs[j])
+            if ok:
                 first = j
                 break
-        lo, hi = (xs[first - 1] if first > 0 else lo), (xs[first] if first < 32 else hi)
+        if first > 0:
+            lo, flo, have_lo = xs[first - 1], ph[first - 1], True
+        if first < 32:
+            hi, fhi, have_hi = xs[first], ph[first], True
     return hi
 
 
