@@ -18,6 +18,18 @@ from test_gpu_parity import MAIN_CTRS, assert_tree_equal  # noqa: E402
 
 
 def run(cases=40, seed=0):
+    saved = {k: os.environ.get(k) for k in list(KNOBS) + ["AZD_DENSE_NO_POOL"]}
+    try:
+        _run(cases, seed)
+    finally:  # whatever happens, the process's environment is what it was
+        for k, v in saved.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
+
+
+def _run(cases, seed):
     rng = random.Random(seed)
     KNOBS = {"AZD_POOL_EARLY_POST": ["0", "1", "2"], "AZD_POOL_EXPRESS_WGS": ["0", "8", "16"], "AZD_POOL_EVAL_WGS": ["24", "64", "100"],
              "AZD_POOL_READY_LANES": ["0", "1"], "AZD_DENSE_POOL_SEARCH_WGS": ["32", "96", "128"], "AZD_DENSE_POOL_ROUNDS": ["1", "4"],
@@ -102,6 +114,8 @@ def run(cases=40, seed=0):
                 left -= k
         if o1.step_form()[0] != "pool":  # (a width the in-kernel evaluator does not take: nothing to compare)
             print("   skipped:", o1.step_form())
+            for k in KNOBS:  # (the case's knobs must not outlive it: they once leaked into the rest of the test session)
+                os.environ.pop(k, None)
             continue
         for k in KNOBS:
             os.environ.pop(k, None)
