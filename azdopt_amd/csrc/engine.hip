@@ -1349,7 +1349,10 @@ static int roll_out_impl(azd_engine *e, const azd::TolTable &t, int n_calls, int
             const double eval_us_per_row = flop / (256.0 * 2400.0) / (fe.bf16 ? 1.85 : 1.0) / 0.33;
             // (a Ramsey call costs the searchers less: no lambda_1, five selections per expansion against eleven; best 126 of 256
             // for config D, 113 cost 10 %, 134 5 % -- gpurun sweep r2m/D_*)
-            const double search_us_per_call = e->a.space == azd::SPACE_RAMSEY ? 3.6 : 4.65;
+            // (round 4: a c21 call costs the searchers a quarter less -- one round trip per selection level, 3.6 rounds of lambda_1 -- and the
+            // measured-feedback split settles at 100-105 of 256 where it used to settle at 89-96; a first guess of 88 cost a process that
+            // makes few launches -- the bench's 20-call window -- 8 %: 27.0 against 29.4 M expansions/s at 88 / 104 evaluator workgroups)
+            const double search_us_per_call = e->a.space == azd::SPACE_RAMSEY ? 3.6 : 3.65;
             n_eval = (int)(e->n_cus * eval_us_per_row / (eval_us_per_row + search_us_per_call) + 0.5);
             // populations well beyond the searching waves keep the evaluator queues deep enough for 32-row batches (two row
             // tiles per weight fragment, where they fit the LDS), which cost an evaluator 1.2 us per row instead of 1.6:

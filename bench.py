@@ -498,6 +498,16 @@ def main():
                                      "frac": ach / (chip_peak * cus / 256.0) if cus else None, "cus": cus, "flop_per_row": flop_per_row,
                                      "note": "rows served per second x the model's flop per row, against the dense matrix-core peak of the CUs "
                                              "the evaluator side holds (%s storage)" % ("fp32" if mlp_dtype == "f32" else "bf16")}
+        if mlp_dtype and form == "pool" and wl["kind"] != "dense" and d.get("EVAL_BATCHES", 0) > 0:
+            # what actually bounds an in-kernel evaluator batch: the workgroup's weight stream from L2 -- every
+            # batch pulls the whole model through one CU's vector-memory path -- against that path's 64 B per clock
+            wbytes = sum(a * b for a, b in zip((space.STATE_DIM,) + HIDDEN, HIDDEN + (space.ACTION_DIM,))) * (4 if mlp_dtype == "f32" else 2)
+            us_per_batch = d["TICKS_BATCH"] / 100.0 / d["EVAL_BATCHES"]
+            out["evaluator_weight_stream"] = {"bound": "l2->cu", "achieved": wbytes / us_per_batch / 1e3, "peak": 64 * 2.4, "unit": "GB/s per evaluator CU",
+                                              "frac": wbytes / us_per_batch / 1e3 / (64 * 2.4), "us_per_batch": us_per_batch,
+                                              "rows_per_batch": d["EVAL_ROWS"] / d["EVAL_BATCHES"], "weight_bytes_per_batch": wbytes,
+                                              "note": "a batch streams the model's weights once through its CU; measured with a vector-ALU consumer as well "
+                                                      "(no MFMA issue at all): the same ~21-25 B per clock under this kernel's load"}
         out["best_cost_run"] = (best_cost_run(az, wl, HIDDEN, AGENTS_PER_GPU, mlp_dtype, args.best_cost_epochs)
                                 if (world == 1 and wl["kind"] == "c21" and mlp_dtype and args.best_cost_epochs > 0 and not args.no_cpu_baseline) else None)
         if not args.no_cpu_baseline and world == 1:  # timed beside the GPU run at N = 1 only
