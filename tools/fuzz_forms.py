@@ -17,6 +17,11 @@ import azdopt_amd as az  # noqa: E402
 from test_gpu_parity import MAIN_CTRS, assert_tree_equal  # noqa: E402
 
 
+KNOBS = {"AZD_POOL_EARLY_POST": ["0", "1", "2"], "AZD_POOL_EXPRESS_WGS": ["0", "8", "16"], "AZD_POOL_EVAL_WGS": ["24", "64", "100"],
+         "AZD_POOL_READY_LANES": ["0", "1"], "AZD_DENSE_POOL_SEARCH_WGS": ["32", "96", "128"], "AZD_DENSE_POOL_ROUNDS": ["1", "4"],
+         "AZD_DENSE_POOL_STREAMS": ["1", "2"]}
+
+
 def run(cases=40, seed=0):
     saved = {k: os.environ.get(k) for k in list(KNOBS) + ["AZD_DENSE_NO_POOL"]}
     try:
@@ -31,10 +36,6 @@ def run(cases=40, seed=0):
 
 def _run(cases, seed):
     rng = random.Random(seed)
-    KNOBS = {"AZD_POOL_EARLY_POST": ["0", "1", "2"], "AZD_POOL_EXPRESS_WGS": ["0", "8", "16"], "AZD_POOL_EVAL_WGS": ["24", "64", "100"],
-             "AZD_POOL_READY_LANES": ["0", "1"], "AZD_DENSE_POOL_SEARCH_WGS": ["32", "96", "128"], "AZD_DENSE_POOL_ROUNDS": ["1", "4"],
-             "AZD_DENSE_POOL_STREAMS": ["1", "2"]}
-
 
     def same(o1, i1, o2, i2, B, tag):
         assert i1 == i2, (tag, i1, i2)
