@@ -31,6 +31,11 @@ def test_bench_line_of_the_default_workload_in_the_drivers_window():
     c = j["cpu_baseline"]
     assert c["kind"] == "port" and c["cores"] >= 1 and c["value"] > 0 and "sample" in c
     assert j["epoch_boundaries_in_timed_region"] == 0 and j["replicas_identical"] is True
+    b = j["best_cost_run"]  # the other half of the metric: the reference driver's loop to lambda_1 + mu < 5.2, beside a frozen-model control
+    assert b["goal"] == 5.2 and b["trained"]["epochs"] >= 1 and b["frozen_control"]["epochs"] == b["trained"]["epochs"]
+    assert b["trained"]["best_cost"] <= b["trained"]["best_cost_after_first_epoch"]
+    w = j["evaluator_weight_stream"]
+    assert w["bound"] == "l2->cu" and 0 < w["frac"] < 1 and w["rows_per_batch"] >= 1
 
 
 def test_bench_line_of_config_e_on_the_pool_searchers():
