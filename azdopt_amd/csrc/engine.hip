@@ -2139,8 +2139,8 @@ int azd_engine_debug_tile_forward(azd_engine *e, const float *states, float *pre
     uint32_t dyn_stride = 0;
     size_t dyn_bytes = 0;
     const char *why = "";
-    if (e->a.space != azd::SPACE_C21 || !e->ev->fused_desc(&fe) || fe.kind != 3 || !azd::pool_plan(e->a, fe, &pool, &dyn_stride, &dyn_bytes, &why)) {
-        azd::g_last_error = "debug_tile_forward: needs the c21 space with an MLP evaluator the pool step can serve";
+    if (e->a.space == azd::SPACE_DENSE || !e->ev->fused_desc(&fe) || fe.kind != 3 || !azd::pool_plan(e->a, fe, &pool, &dyn_stride, &dyn_bytes, &why)) {
+        azd::g_last_error = "debug_tile_forward: needs the c21 or the Ramsey space with an MLP evaluator the pool step can serve";
         return AZD_ERR_INVALID_ARGUMENT;
     }
     float *d_in = nullptr, *d_out = nullptr;

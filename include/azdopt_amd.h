@@ -390,7 +390,8 @@ int azd_engine_read_state_vecs(azd_engine *e, float *state_vecs); /* batch*state
 int azd_engine_read_predictions(azd_engine *e, float *h_theta);   /* last h_theta, batch*action_dim */
 /* Test entry: `rows` prediction rows exactly as the CU-resident step forms' in-kernel evaluator computes them (the same sums in
  * the same order; the model call of model/dfdx.rs:69-84), for state vectors the host hands over: what a checker feeds its
- * restatement with to follow a whole launch of the product kernel with the real model.  c21 space, MLP evaluator. */
+ * restatement with to follow a whole launch of the product kernel with the real model.  c21 / Ramsey space, MLP evaluator
+ * (f32 or bf16 storage). */
 int azd_engine_debug_tile_forward(azd_engine *e, const float *states, float *predictions, int rows);
 
 /* Introspection (SearchTree::{nodes, positions, node_data}, tree/mod.rs:302-315;

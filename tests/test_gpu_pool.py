@@ -347,6 +347,54 @@ def test_product_pool_kernel_with_the_real_model_over_whole_epochs_against_the_o
             oe.reset_end(opt.predictions())
 
 
+def _follow_with_the_oracle(opt, oe, tol, calls):
+    """one launch of `calls` calls on the device; the oracle, call by call, fed with the in-kernel evaluator's rows of its own states"""
+    io = 0
+    for _ in range(calls):
+        oe.rollout_begin(*tol)
+        io += oe.rollout_end(opt.debug_tile_forward(oe.state_vecs()))
+    ig = opt.par_roll_out_episodes(tol, n_calls=calls)
+    assert ig == io
+    cg, co = opt.counters(), oe.counters()
+    for k in MAIN_CTRS:
+        assert cg[k] == co[k], (k, cg[k], co[k])
+    assert np.array_equal(opt.state_vecs(), oe.state_vecs())
+
+
+def test_product_pool_kernel_with_bf16_storage_over_a_whole_epoch_against_the_oracle(az, orc):
+    """BASELINE configs[2]'s evaluator (bf16 weight / activation storage, f32 accumulate) in the product kernel, 800 calls in one
+    launch, against the oracle fed with the same evaluator's rows (debug_tile_forward runs the bf16 tile task)"""
+    n, B, seed, calls = 19, 256, 17, 800
+    space = az.ROTModifyParentsOnce(n)
+    roots = space.generate_roots(seed, B)
+    model = az.ActionModel(B, space.STATE_DIM, space.ACTION_DIM, hidden=(256, 256, 256), seed=seed, dtype="bf16")
+    opt = az.NablaOptimizer.par_new(space, roots, model, B, pool_step=True)
+    oe = orc.Engine(n, B, threads=8)
+    oe.new_begin(*roots)
+    oe.new_end(opt.predictions())
+    _follow_with_the_oracle(opt, oe, TOL_REF, calls)
+    assert opt.step_form() == ("pool", "")
+    for i in range(0, B, 2):
+        assert_tree_equal(opt.get_tree(i), oe.export_tree(i), f"agent {i}")
+
+
+def test_asynchronous_step_with_the_real_model_in_one_launch_against_the_oracle(az, orc):
+    """k_async (agents bound to waves, the evaluator served by the waiting waves of the workgroup: the default below 256 agents)
+    with the real model, 300 calls in one launch, against the oracle: its tile task is the pool step's, so the same rows feed it"""
+    n, B, seed, calls = 19, 96, 23, 300
+    space = az.ROTModifyParentsOnce(n)
+    roots = space.generate_roots(seed, B)
+    model = az.ActionModel(B, space.STATE_DIM, space.ACTION_DIM, hidden=(256, 256, 256), seed=seed)
+    opt = az.NablaOptimizer.par_new(space, roots, model, B, pool_step=False)
+    oe = orc.Engine(n, B, threads=8)
+    oe.new_begin(*roots)
+    oe.new_end(opt.predictions())
+    _follow_with_the_oracle(opt, oe, TOL_REF, calls)
+    assert opt.step_form()[0] == "async"
+    for i in range(B):
+        assert_tree_equal(opt.get_tree(i), oe.export_tree(i), f"agent {i}")
+
+
 @pytest.mark.parametrize("model_kind", ["hash", "mlp"])
 def test_pool_abort_is_taken_over_by_the_async_step(az, orc, model_kind, monkeypatch):
     """PoolCtl::abort (a wait ran into its bound) no longer fails the call: the asynchronous step takes the launch over

@@ -279,3 +279,29 @@ def test_ramsey_pool_abort_taken_over_by_k_async_with_a_resume_table_against_the
     assert np.array_equal(opt.state_vecs(), oe.state_vecs())
     for i in range(0, B, 3):
         assert_tree_equal(opt.get_tree(i), oe.export_tree(i), f"agent {i}")
+
+
+def test_ramsey_product_pool_kernel_with_the_real_model_in_one_launch_against_the_oracle(az, orc):
+    """config D's kernel k_pool<RamseySpace<5>, 0> with the real 3 x 256 model, 250 calls in one launch at 256 agents, against the
+    oracle fed -- call by call -- with the rows of its own states as the in-kernel evaluator computes them (debug_tile_forward)"""
+    n, sizes, weights, B, seed, calls = 17, [4, 4], [1.0, 1.0], 256, 29, 250
+    tol = ([200, 200, 100, 100, 50, 50, 25, 25], 10)
+    space = az.RamseySpaceNoEdgeRecolor(n, sizes, weights)
+    roots = space.generate_roots(seed, B)
+    model = az.ActionModel(B, space.STATE_DIM, space.ACTION_DIM, hidden=(256, 256, 256), seed=seed)
+    opt = az.NablaOptimizer.par_new(space, roots, model, B, pool_step=True, prediction_capacity=131072)
+    oe = orc.Engine(n, B, threads=8, ramsey=(sizes, weights))
+    oe.new_begin(*roots)
+    oe.new_end(opt.predictions())
+    io = 0
+    for _ in range(calls):
+        oe.rollout_begin(*tol)
+        io += oe.rollout_end(opt.debug_tile_forward(oe.state_vecs()))
+    ig = opt.par_roll_out_episodes(tol, n_calls=calls)
+    assert opt.step_form() == ("pool", "") and ig == io
+    cg, co = opt.counters(), oe.counters()
+    for k in MAIN_CTRS:
+        assert cg[k] == co[k], (k, cg[k], co[k])
+    assert np.array_equal(opt.state_vecs(), oe.state_vecs())
+    for i in range(0, B, 2):
+        assert_tree_equal(opt.get_tree(i), oe.export_tree(i), f"agent {i}")
