@@ -177,7 +177,10 @@ typedef struct azd_engine_config {
     int n;             /* vertices N (c21: 4..AZD_C21_MAX_N; Ramsey: 3..AZD_RAMSEY_MAX_N) */
     int batch;         /* BATCH: agents (trees) owned by this engine / GPU */
     int device;        /* HIP device ordinal */
-    /* per-tree arena capacities; 0 = default sized for 800 calls per epoch */
+    /* per-tree arena capacities; 0 = default sized for 800 calls per epoch (4096 / 8192 / 32768).  Upper limits, from what a
+     * prediction record packs (node ids 16 bits, arc ids 16, a node's first prediction 20): 65536 nodes, 65535 arcs, 1048576
+     * predictions per tree; ACTION_DIM <= 4096, <= 2047 actions per node.  Beyond them azd_engine_create returns
+     * AZD_ERR_INVALID_ARGUMENT; an arena that fills during a run stops its agent and surfaces as AZD_ERR_CAPACITY. */
     int node_capacity;
     int arc_capacity;
     int prediction_capacity;
