@@ -276,6 +276,7 @@ __global__ __launch_bounds__(256, MI == 1 ? 4 : 2) void k_gemm_bf16(const float 
 }
 
 #include "gemm_bf16_glds.inc"
+#include "gemm_bf16_hidden2.inc"
 
 // ---- bf16 weight storage: w16 = RNE(params) in 16-bit words, params_q = the same values widened back
 // to f32 (what the f32 GEMM path multiplies with, so that it computes what the bf16 MFMA path computes)
@@ -457,6 +458,7 @@ struct MlpEvaluator : azd_evaluator {
     float *d_wpk = nullptr;        // fragment-major weights for the asynchronous step (f32 words / bf16 halves)
     std::vector<int64_t> p_off;
     int64_t n_packed = 0;
+    bool fuse_hidden2 = true; // two consecutive 512-wide hidden layers in one launch (gemm_bf16_hidden2.inc; AZD_MLP_FUSE_HIDDEN=0: layer by layer)
     int gemm_small_below = 1024; // bf16 GEMM: grids of fewer 128 x 128 tiles than this use 64 x 128 tiles (AZD_GEMM_SMALL_BELOW overrides: experiments)
 
     ~MlpEvaluator() override {
@@ -515,6 +517,10 @@ struct MlpEvaluator : azd_evaluator {
         }
         return AZD_OK;
     }
+    // layers l and l + 1 are both 512 -> 512 hidden layers whose input is an activation buffer in batch order: one fused launch
+    bool hidden_pair(int l) const {
+        return fuse_hidden2 && l >= 1 && l + 2 < L && dims[(size_t)l] == HF_H && dims[(size_t)l + 1] == HF_H && dims[(size_t)l + 2] == HF_H;
+    }
     // The bf16 forward on the LDS-DMA GEMM (gemm_bf16_glds.inc): x16 = the input rows as bf16 with pitch kp[0] (the producer's own
     // copy: azd_evaluator::write_predictions_dev16), or null: converted here from the f32 rows.  Same sums as k_gemm_bf16.
     // act_row0: the rows of the activation buffers this call may use (write_predictions_rows: disjoint ranges run concurrently)
@@ -527,6 +533,14 @@ struct MlpEvaluator : azd_evaluator {
         }
         for (int l = 0; l < L; ++l) {
             const bool last = l == L - 1;
+            if (hidden_pair(l)) {
+                uint16_t *y2 = d_act16[(size_t)l + 2] + (size_t)act_row0 * HF_H;
+                launch_hidden2<false>(st, x16, HF_H, d_w16p + wp_off[(size_t)l], d_w16p + wp_off[(size_t)l + 1], HF_H, d_params + b_off[(size_t)l],
+                                      d_params + b_off[(size_t)l + 1], y2, HF_H, batch, nullptr);
+                x16 = y2;
+                l += 1;
+                continue;
+            }
             void *y = last ? (void *)d_p : (void *)(d_act16[(size_t)l + 1] + (size_t)act_row0 * kp[(size_t)l + 1]);
             launch_gemm16(st, x16, kp[(size_t)l], d_w16p + wp_off[(size_t)l], kp[(size_t)l], y, last ? dims[(size_t)L] : kp[(size_t)l + 1], batch,
                           dims[(size_t)l + 1], kp[(size_t)l], last ? final_act : AZD_ACT_RELU, last ? 0 : 1, d_params + b_off[(size_t)l], n_cus);
@@ -616,6 +630,14 @@ struct MlpEvaluator : azd_evaluator {
         const uint16_t *x16 = d_s16;
         for (int l = 0; l < L; ++l) {
             const bool last = l == L - 1;
+            if (hidden_pair(l)) {
+                uint16_t *y2 = d_act16[(size_t)l + 2] + (size_t)act_row0 * HF_H;
+                launch_hidden2<true>(st, x16, HF_H, d_w16p + wp_off[(size_t)l], d_w16p + wp_off[(size_t)l + 1], HF_H, d_params + b_off[(size_t)l],
+                                     d_params + b_off[(size_t)l + 1], y2, HF_H, max_rows, d_count);
+                x16 = y2;
+                l += 1;
+                continue;
+            }
             void *y = last ? (void *)d_p : (void *)(d_act16[(size_t)l + 1] + (size_t)act_row0 * kp[(size_t)l + 1]);
             launch_gemm16_ext(st, x16, kp[(size_t)l], d_w16p + wp_off[(size_t)l], kp[(size_t)l], y, last ? dims[(size_t)L] : kp[(size_t)l + 1], max_rows,
                               dims[(size_t)l + 1], kp[(size_t)l], last ? final_act : AZD_ACT_RELU, last ? 0 : 1, d_params + b_off[(size_t)l], n_cus, d_count,
@@ -840,6 +862,7 @@ azd_evaluator *make_mlp_evaluator(int device, int max_batch, int state_dim, int 
     m->dims.push_back(action_dim);
     m->final_act = final_act;
     if (const char *env = getenv("AZD_GEMM_SMALL_BELOW")) m->gemm_small_below = atoi(env);
+    if (const char *env = getenv("AZD_MLP_FUSE_HIDDEN")) m->fuse_hidden2 = atoi(env) != 0;
     m->adam = *adam;
     m->max_batch = max_batch;
     int64_t off = 0;

@@ -100,3 +100,22 @@ def test_bf16_search_parity_and_in_kernel_predictions(az, orc, persistent):
     for i in range(B):
         assert_tree_equal(opt.get_tree(i), oe.export_tree(i), f"agent {i}")
     assert np.isfinite(opt.par_update_model(5))
+
+
+@pytest.mark.parametrize("B", [200, 77, 1])
+def test_fused_hidden_layers_equal_the_layer_by_layer_forward(az, monkeypatch, B):
+    """two 512-wide hidden layers in one launch (k_hidden2_fused: 32-row panels, activations in LDS, both weight matrices
+    streamed through one ring) give every prediction the same bits as one k_gemm16 launch per layer; batches that are not
+    multiples of the 32-row panel"""
+    dims = (3676, 512, 512, 512, 2450)
+    rng = np.random.default_rng(7)
+    x = rng.integers(0, 3, (B, dims[0])).astype(F) * (rng.random((B, dims[0])) < 0.3)
+    ys = []
+    for fuse in ("1", "0"):
+        monkeypatch.setenv("AZD_MLP_FUSE_HIDDEN", fuse)
+        m = az.ActionModel(B, dims[0], dims[-1], hidden=dims[1:-1], seed=11, dtype="bf16")
+        y = np.zeros((B, dims[-1]), F)
+        m.write_predictions(x, y)
+        ys.append(y)
+    assert np.array_equal(ys[0].view(np.uint32), ys[1].view(np.uint32))
+    assert np.max(np.abs(ys[0] - reference_forward(m.get_params(), dims, x))) < BF16_ATOL
