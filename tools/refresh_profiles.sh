@@ -46,7 +46,8 @@ if has sq; then
   echo sq done
 fi
 if has gemm; then
-  { timeout -k 10 200 python tools/time_gemm16.py; echo "# zero-filled operands (they read higher; for comparison with figures quoted that way):"; AZD_GEMM_ZEROS=1 timeout -k 10 200 python tools/time_gemm16.py 8192 4096 4096; for dt in bf16 f32; do timeout -k 10 100 python tools/time_gemm.py $dt 8192; timeout -k 10 100 python tools/time_gemm.py $dt 65536 304,256,256,256,152; timeout -k 10 100 python tools/time_gemm.py $dt 8192 4096,4096,4096; done; AZD_GEMM_OLD=1 timeout -k 10 100 python tools/time_gemm.py bf16 8192; } > $O/gemm.txt 2>&1
+  { timeout -k 10 200 python tools/time_gemm16.py; echo "# zero-filled operands (they read higher; for comparison with figures quoted that way):"; AZD_GEMM_ZEROS=1 timeout -k 10 200 python tools/time_gemm16.py 8192 4096 4096; for dt in bf16 f32; do timeout -k 10 100 python tools/time_gemm.py $dt 8192; timeout -k 10 100 python tools/time_gemm.py $dt 65536 304,256,256,256,152; timeout -k 10 100 python tools/time_gemm.py $dt 8192 4096,4096,4096; done; AZD_GEMM_OLD=1 timeout -k 10 100 python tools/time_gemm.py bf16 8192;
+    echo "# config E's whole forward, hidden layers fused (k_hidden2_fused) and layer by layer:"; timeout -k 10 100 python tools/time_forward16.py; AZD_MLP_FUSE_HIDDEN=0 timeout -k 10 100 python tools/time_forward16.py; } > $O/gemm.txt 2>&1
   echo gemm done
 fi
 if has split; then
