@@ -408,7 +408,11 @@ int azd_engine_agent_state(azd_engine *e, int agent, uint8_t *parents, uint64_t 
                            uint64_t *path, uint32_t *state_pos, double *lambda_1,
                            int *matching_size);
 int azd_engine_counters(azd_engine *e, uint64_t *out /* [AZD_CTR_COUNT] */);
-/* the same counters per agent, unreduced: out[batch][AZD_CTR_COUNT] (load-balance diagnostics) */
+/* the same counters per agent, unreduced: out[batch][AZD_CTR_COUNT] (load-balance diagnostics).  The launch-per-phase and
+ * asynchronous forms attribute every count to its agent.  The pool step of the product build adds a searcher wave's counts once,
+ * when the wave leaves the launch, to ONE agent's block (the sums and maxima of azd_engine_counters are the same; the per-call
+ * read-modify-write of the agent's block was a dependent round trip on the wave's time): per-agent attribution under the pool
+ * step is the diagnostic build's (make PROFILE=1, tools/slow_agents.py). */
 int azd_engine_agent_counters(azd_engine *e, uint64_t *out);
 /* ms of GPU time spent in the tree kernels / evaluator since creation (HIP events
  * on the engine's stream; enabled by azd_engine_set_timing) */
