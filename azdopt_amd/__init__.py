@@ -5,7 +5,7 @@ NablaOptimizer (optimizer/mod.rs), NablaModel / ActionModel / TrivialModel (mode
 space ROTModifyParentsOnce and the ActionSet path with its symmetry axioms."""
 from ._lib import ACT_NONE, ACT_RELU, ACT_SIGMOID, AzdError, build, lib  # noqa: F401
 from .model import ActionModel, HashStreamModel, NablaModel, TrivialModel  # noqa: F401
-from .optimizer import ArgminData, DenseArgminData, NablaOptimizer, RamseyArgminData, TreeView  # noqa: F401
+from .optimizer import ArgminData, DenseArgminData, NablaOptimizer, RamseyArgminData, TreeView, tree_capacities  # noqa: F401
 from . import sinks  # noqa: F401
 from .space import Layered  # noqa: F401
 from .space import DenseGraphSpace  # noqa: F401

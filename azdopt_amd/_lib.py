@@ -124,6 +124,7 @@ def lib():
     sig("azd_engine_par_reset_trees", C.c_int, vp, vp, vp)
     sig("azd_engine_argmin_data", C.c_int, vp, C.POINTER(Argmin))
     sig("azd_engine_agent_counters", C.c_int, vp, vp)
+    sig("azd_engine_agent_counters_per_agent", C.c_int, vp)
     sig("azd_engine_ramsey_argmin_data", C.c_int, vp, C.POINTER(RamseyArgmin))
     sig("azd_engine_ramsey_agent_counts", C.c_int, vp, C.c_int, vp, vp)
     sig("azd_ramsey_state_dim", C.c_int, C.c_int, C.c_int)

@@ -141,6 +141,8 @@ struct azd_engine {
     bool log_clean = false;              // d_log_key is all ones (k_argmin_log1 leaves it so; the barrier step and an abort do not)
     bool pool_clean = false;             // PoolCtl, the queue slots and the join counters are zero (a completed pool launch leaves them so)
     bool pool_failed = false;            // a pool launch aborted: this engine takes the asynchronous step from then on
+    bool counters_by_wave = false;       // a pool launch of the product build has run since the counters were cleared: the blocks of
+                                         // azd_engine_agent_counters then hold what searcher WAVES counted, not what agents did
     uint32_t *d_resume = nullptr;        // [B] take-over of an aborted pool launch by k_async (StepLaunch::resume)
     unsigned long long *d_log_key = nullptr;
     uint32_t *d_log_node = nullptr;
@@ -704,11 +706,27 @@ int azd_engine_create(azd_engine **out, const azd_engine_config *cfg, azd_evalua
     a.arc_cap = cfg->arc_capacity > 0 ? (uint32_t)cfg->arc_capacity : 8192u;
     a.pred_cap = cfg->prediction_capacity > 0 ? (uint32_t)cfg->prediction_capacity : 32768u;
     a.ht_cap = (uint32_t)next_pow2((int)(2 * a.node_cap));
-    // what a prediction record packs (engine_types.h: PredRec): child node 16 bits, arc id 16, child's first prediction 20, action id 12
-    if (a.node_cap > 65536u || a.arc_cap > 65535u || a.pred_cap > (1u << 20) || a.A > 4096) {
-        azd::g_last_error = "tree capacities beyond the record format: node_capacity <= 65536, arc_capacity <= 65535, prediction_capacity <= 1048576, ACTION_DIM <= 4096";
-        delete e;
-        return AZD_ERR_INVALID_ARGUMENT;
+    // what the packed records hold (engine_types.h: PredRec / node_pack): child node 16 bits, arc id 16 (0xFFFF = none), a child's first
+    // prediction 20, action id 12, actions per node 11, n_t 20 (one per arc at most), exhausted 12 (one per action at most).  The
+    // reference's u32 indices (petgraph NodeIndex / EdgeIndex, tree/mod.rs:28-32) have no such limits: a configuration beyond them is
+    // refused here, naming the argument, instead of corrupting a neighbouring bit field later.
+    static_assert(AZD_DENSE_MAX_SLOTS <= 2047 && azd::MAX_NODE_ACTIONS <= 2047, "actions per node must fit PredRec's 11-bit count");
+    static_assert(AZD_MAX_NODE_CAPACITY == 65536 && AZD_MAX_ARC_CAPACITY == 65535 && AZD_MAX_PREDICTION_CAPACITY == (1 << 20), "limits of the packed records");
+    {
+        const char *bad = nullptr;
+        static thread_local char msg[256];
+        const long per_node = dense ? (long)e->dense_slots : ramsey ? (long)a.E * (a.C - 1) : (long)a.A;
+        if (a.node_cap > (uint32_t)AZD_MAX_NODE_CAPACITY) snprintf(msg, sizeof msg, "node_capacity %u is beyond the record format (<= %d)", a.node_cap, AZD_MAX_NODE_CAPACITY), bad = msg;
+        else if (a.arc_cap > (uint32_t)AZD_MAX_ARC_CAPACITY) snprintf(msg, sizeof msg, "arc_capacity %u is beyond the record format (<= %d)", a.arc_cap, AZD_MAX_ARC_CAPACITY), bad = msg;
+        else if (a.pred_cap > (uint32_t)AZD_MAX_PREDICTION_CAPACITY) snprintf(msg, sizeof msg, "prediction_capacity %u is beyond the record format (<= %d)", a.pred_cap, AZD_MAX_PREDICTION_CAPACITY), bad = msg;
+        else if (a.A > 4096) snprintf(msg, sizeof msg, "ACTION_DIM %d is beyond the record format (<= 4096)", a.A), bad = msg;
+        // (an upper bound of what a node can hold: c21 / Ramsey nodes are further limited to MAX_NODE_ACTIONS at run time, FLAG_NODE_ACTIONS)
+        else if (per_node > 2047) snprintf(msg, sizeof msg, "%ld legal actions per node are beyond the record format (<= 2047)", per_node), bad = msg;
+        if (bad) {
+            azd::g_last_error = bad;
+            delete e;
+            return AZD_ERR_INVALID_ARGUMENT;
+        }
     }
     const size_t B = (size_t)a.B;
 #define TRY(x)              \
@@ -914,6 +932,7 @@ int azd_engine_par_new_begin(azd_engine *e, const uint8_t *parents, const uint64
     if (st) return st;
     const azd::Arenas &a = e->a;
     AZD_HIP(hipMemsetAsync(a.counters, 0, (size_t)a.B * azd::NUM_COUNTERS * 8, e->stream));
+    e->counters_by_wave = false;
     AZD_HIP(hipMemsetAsync(a.status, 0, sizeof(azd::StatusRec), e->stream));
     e->seen_improved = 0;
     azd::launch_init_roots(a, e->d_stage_parents, e->d_stage_perm, e->stream);
@@ -1186,6 +1205,9 @@ static int dense_pool_run(azd_engine *e, const azd::TolTable &t, int n_calls, bo
         sl.window = 0;
         e->time_begin(0);
         azd::dense_launch_pool_search(a, e->d_pargs, sl, n_search, waves, dyn_stride, dyn_bytes, e->stream);
+#ifndef AZD_PHASE_PROFILE
+        e->counters_by_wave = true;
+#endif
         e->time_end();
         AZD_HIP(hipGetLastError());
         AZD_HIP(hipEventRecord(e->ext_done, e->stream));
@@ -1512,8 +1534,12 @@ static int roll_out_impl(azd_engine *e, const azd::TolTable &t, int n_calls, int
             sl.hashed = fe.kind == 4;
             sl.window = ahead ? 1 : 0;
             e->time_begin(0);
-            if (use_pool) azd::launch_pool(e->a, e->d_pargs, sl, fe.params, fe.wpk, pool_blocks, dyn_stride, dyn_bytes, e->stream);
-            else if (use_async) azd::launch_async(e->a, e->d_pargs, sl, fe.params, fe.wpk, dyn_stride, dyn_bytes, e->stream);
+            if (use_pool) {
+                azd::launch_pool(e->a, e->d_pargs, sl, fe.params, fe.wpk, pool_blocks, dyn_stride, dyn_bytes, e->stream);
+#ifndef AZD_PHASE_PROFILE
+                e->counters_by_wave = true;
+#endif
+            } else if (use_async) azd::launch_async(e->a, e->d_pargs, sl, fe.params, fe.wpk, dyn_stride, dyn_bytes, e->stream);
             else {
                 azd::launch_persist(e->a, e->d_pargs, sl, e->d_log_node, dyn_stride, dyn_bytes, e->stream);
                 e->log_clean = false;
@@ -2144,15 +2170,17 @@ int azd_engine_debug_tile_forward(azd_engine *e, const float *states, float *pre
         return AZD_ERR_INVALID_ARGUMENT;
     }
     float *d_in = nullptr, *d_out = nullptr;
-    AZD_HIP(hipMalloc(&d_in, (size_t)rows * e->a.S * 4));
-    AZD_HIP(hipMalloc(&d_out, (size_t)rows * e->a.A * 4));
-    AZD_HIP(hipMemcpyAsync(d_in, states, (size_t)rows * e->a.S * 4, hipMemcpyHostToDevice, e->stream));
-    azd::launch_tile_forward(fe, pool, rows, d_in, d_out, e->stream);
-    AZD_HIP(hipMemcpyAsync(predictions, d_out, (size_t)rows * e->a.A * 4, hipMemcpyDeviceToHost, e->stream));
-    AZD_HIP(hipStreamSynchronize(e->stream));
+    hipError_t he = hipMalloc(&d_in, (size_t)rows * e->a.S * 4);
+    const char *what = "hipMalloc";
+    if (he == hipSuccess) he = hipMalloc(&d_out, (size_t)rows * e->a.A * 4);
+    if (he == hipSuccess) what = "hipMemcpyAsync", he = hipMemcpyAsync(d_in, states, (size_t)rows * e->a.S * 4, hipMemcpyHostToDevice, e->stream);
+    if (he == hipSuccess) what = "k_tile_forward", he = azd::launch_tile_forward(fe, pool, rows, d_in, d_out, e->stream);
+    if (he == hipSuccess) what = "hipMemcpyAsync", he = hipMemcpyAsync(predictions, d_out, (size_t)rows * e->a.A * 4, hipMemcpyDeviceToHost, e->stream);
+    if (he == hipSuccess) what = "hipStreamSynchronize", he = hipStreamSynchronize(e->stream);
+    else (void)hipStreamSynchronize(e->stream); // nothing of this call may still be running on the buffers freed below
     (void)hipFree(d_in);
     (void)hipFree(d_out);
-    return AZD_OK;
+    return he == hipSuccess ? AZD_OK : azd::hip_fail(he, what);
 }
 int azd_engine_read_predictions(azd_engine *e, float *out) {
     if (!e || !out) return AZD_ERR_INVALID_ARGUMENT;
@@ -2320,6 +2348,7 @@ int azd_engine_agent_counters(azd_engine *e, uint64_t *out) {
     AZD_HIP(hipMemcpy(out, e->a.counters, (size_t)e->a.B * azd::NUM_COUNTERS * 8, hipMemcpyDeviceToHost));
     return AZD_OK;
 }
+int azd_engine_agent_counters_per_agent(azd_engine *e) { return e ? (e->counters_by_wave ? 0 : 1) : AZD_ERR_INVALID_ARGUMENT; }
 
 int azd_engine_set_timing(azd_engine *e, int enabled) {
     if (!e) return AZD_ERR_INVALID_ARGUMENT;

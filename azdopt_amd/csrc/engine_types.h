@@ -65,7 +65,7 @@ struct __attribute__((aligned(16))) PredRec {
     uint32_t w0, w1, w2, w3;
 };
 static_assert(sizeof(PredRec) == 16, "PredRec must be 16 B");
-#if defined(__HIPCC__) || defined(__CUDACC__)
+#if defined(__HIPCC__)
 #define AZD_HD __host__ __device__ inline
 #else
 #define AZD_HD inline
@@ -353,7 +353,7 @@ int ramsey_pool_max_resident(const Arenas &a, size_t dyn_bytes, int n_cus);
 // after an aborted pool launch: resume[t] for k_async (StepLaunch::resume) from the trees and PoolArgs::pend
 void launch_pool_resume_scan(const Arenas &a, const PoolArgs &pool, int n_calls, uint32_t *resume, void *stream);
 // test entry: the in-kernel evaluator's forward (pool_eval's staging + mlp_tile_task) for rows given by the host
-void launch_tile_forward(const FusedEval &ev, const PoolArgs &pool, int n_rows, const float *states, float *out, void *stream);
+hipError_t launch_tile_forward(const FusedEval &ev, const PoolArgs &pool, int n_rows, const float *states, float *out, void *stream);
 bool ramsey_pool_plan(const Arenas &a, const FusedEval &ev, PoolArgs *pool, uint32_t *dyn_stride, size_t *dyn_bytes, const char **why = nullptr);
 void ramsey_launch_pool(const Arenas &a, const PersistArgs *d_args, const StepLaunch &sl, const float *params,
                         const void *wpk, int n_blocks, uint32_t dyn_stride, size_t dyn_bytes, void *stream);

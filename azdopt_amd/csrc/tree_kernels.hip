@@ -106,11 +106,13 @@ __global__ __launch_bounds__(PERSIST_WAVES * 64) void k_tile_forward(const Fused
         out[(size_t)(first + r) * A + c] = rows.out(r)[c];
     }
 }
-void launch_tile_forward(const FusedEval &ev, const PoolArgs &pool, int n_rows, const float *states, float *out, void *stream) {
+hipError_t launch_tile_forward(const FusedEval &ev, const PoolArgs &pool, int n_rows, const float *states, float *out, void *stream) {
     const size_t dyn_bytes = (size_t)pool.eval_stride * sizeof(float) * PERSIST_WAVES;
-    if (hipFuncSetAttribute((const void *)k_tile_forward, hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn_bytes) != hipSuccess) return;
+    hipError_t he = hipFuncSetAttribute((const void *)k_tile_forward, hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn_bytes);
+    if (he != hipSuccess) return he;
     k_tile_forward<<<dim3((n_rows + PERSIST_WAVES - 1) / PERSIST_WAVES), dim3(PERSIST_WAVES * 64), dyn_bytes, (hipStream_t)stream>>>(
         ev, ev.params, ev.wpk, pool.eval_stride, pool.eval_out_off, n_rows, states, out);
+    return hipGetLastError(); // (a launch that was refused -- LDS, grid -- must not leave the caller copying an unwritten buffer back)
 }
 template <class SP>
 static void q_pool_resident(int *out, size_t dyn_bytes) {

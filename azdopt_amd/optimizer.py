@@ -52,6 +52,25 @@ class TreeView:
         self.__dict__.update(kw)
 
 
+MAX_NODE_CAPACITY, MAX_ARC_CAPACITY, MAX_PREDICTION_CAPACITY = 65536, 65535, 1 << 20  # include/azdopt_amd.h: AZD_MAX_*_CAPACITY
+
+
+def tree_capacities(episodes, max_actions_per_node):
+    """Arena capacities for an epoch of `episodes` calls per tree (a call adds one node, a handful of arcs -- the new arc plus the
+    transpositions on the way -- and one node's predictions), as keyword arguments of `NablaOptimizer.par_new`.  The packed
+    records limit a tree to 65536 nodes, 65535 arcs and 2^20 predictions (the reference's u32 indices do not): an epoch beyond them
+    is refused HERE, naming the argument, rather than by azd_engine_create."""
+    node = max(4096, 2 * episodes + 64)  # one expansion per call, plus the terminal nodes met on the way
+    arc = max(8192, 3 * episodes + 64)
+    pred = max(32768, (episodes + 1) * max_actions_per_node + 128)
+    for name, want, limit in (("node_capacity", node, MAX_NODE_CAPACITY), ("prediction_capacity", pred, MAX_PREDICTION_CAPACITY)):
+        if want > limit:
+            raise ValueError(f"{episodes} episodes per epoch need {name} = {want}, beyond the record format's {limit}: "
+                             f"use at most {(limit - 64) // 2 if name == 'node_capacity' else (limit - 128) // max_actions_per_node - 1} episodes per epoch")
+    # arcs: 3 per call is a generous estimate, not a need; an epoch that does run out stops its agent with AZD_ERR_CAPACITY
+    return dict(node_capacity=node, arc_capacity=min(arc, MAX_ARC_CAPACITY), prediction_capacity=pred)
+
+
 class NablaOptimizer:
     """NablaOptimizer<Space, M, P>; P = ActionSet (default), ActionMultiset, ActionSequence, OrderedActionSet.
 
@@ -293,8 +312,13 @@ class NablaOptimizer:
         _lib.check(self._L.azd_engine_counters(self._h, _lib.ptr(out)), "counters")
         return {k: int(out[v]) for k, v in _lib.CTR.items()}
 
-    def agent_counters(self):
-        """per-agent counters, unreduced: dict name -> uint64 array [batch]"""
+    def agent_counters(self, allow_wave_blocks=False):
+        """per-agent counters, unreduced: dict name -> uint64 array [batch].  After a pool launch of the product build the blocks
+        hold what searcher WAVES counted (only sums / maxima mean anything): refused then unless `allow_wave_blocks` -- per-agent
+        attribution under the pool step is the diagnostic build's (make PROFILE=1), or run with pool_step=False."""
+        if not allow_wave_blocks and self._L.azd_engine_agent_counters_per_agent(self._h) == 0:
+            raise RuntimeError("agent_counters: the pool step of the product build attributes counters to searcher waves, not agents "
+                               "(use counters() for the sums, the PROFILE build or pool_step=False for per-agent values)")
         out = np.zeros((self.batch, _lib.CTR_COUNT), np.uint64)
         _lib.check(self._L.azd_engine_agent_counters(self._h, _lib.ptr(out)), "agent_counters")
         return {k: out[:, v].copy() for k, v in _lib.CTR.items()}

@@ -45,9 +45,8 @@ def main():
     kmin, kmax = 5, space.ACTION_DIM // 2                    # :85
     roots = space.generate_roots(args.seed, args.batch, kmin=kmin, kmax=kmax)
     # arenas for one epoch's tree at its largest: a node per episode, at most kmax predictions per node (the reference's Vecs grow)
-    opt = az.NablaOptimizer.par_new(space, roots, model, args.batch, node_capacity=max(4096, args.episodes + 64),
-                                    arc_capacity=max(8192, 3 * args.episodes + 64),
-                                    prediction_capacity=max(32768, (args.episodes + 1) * kmax + 128))
+    # (tree_capacities names the limits of the packed records: 65536 nodes, 65535 arcs, 2^20 predictions per tree)
+    opt = az.NablaOptimizer.par_new(space, roots, model, args.batch, **az.tree_capacities(args.episodes, kmax))
 
     def process_argmin(argmin, step):
         cost = argmin.cost

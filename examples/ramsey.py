@@ -44,8 +44,7 @@ def main():
         writer = sinks.TensorboardWriter.create(d["tag"])
     kmin, kmax = d["kmin"], space.default_permitted_range()[1]   # ..=(E / 2), capped by what a node holds
     C = len(d["sizes"])
-    caps = dict(node_capacity=episodes * 2 + 64, arc_capacity=episodes * 3 + 64,
-                prediction_capacity=(episodes + 1) * kmax * (C - 1) + 128)
+    caps = az.tree_capacities(episodes, kmax * (C - 1))  # (limits of the packed records: 65536 nodes, 65535 arcs, 2^20 predictions)
     opt = az.NablaOptimizer.par_new(space, space.generate_roots(args.seed, batch, kmin=kmin, kmax=kmax), model, batch, **caps)
 
     def process_argmin(argmin, step):

@@ -172,6 +172,13 @@ uint64_t azd_evaluator_calls(azd_evaluator *ev);
 /* ------------------------------------------------------------------------- */
 typedef struct azd_engine azd_engine;
 
+/* Upper limits of the per-tree arenas (what the packed prediction record holds; the reference's petgraph indices are u32 and
+ * have none): azd_engine_create refuses a configuration beyond them with AZD_ERR_INVALID_ARGUMENT and an azd_last_error()
+ * that names the argument. */
+#define AZD_MAX_NODE_CAPACITY 65536
+#define AZD_MAX_ARC_CAPACITY 65535
+#define AZD_MAX_PREDICTION_CAPACITY (1 << 20)
+
 typedef struct azd_engine_config {
     int space_id;      /* AZD_SPACE_C21 or AZD_SPACE_RAMSEY */
     int n;             /* vertices N (c21: 4..AZD_C21_MAX_N; Ramsey: 3..AZD_RAMSEY_MAX_N) */
@@ -300,7 +307,9 @@ enum { /* indices into azd_engine_counters' output */
     AZD_CTR_EVAL_ROWS = 26,
     AZD_CTR_EVAL_TILES = 27,
     AZD_CTR_TICKS_TILES = 28,   /* diagnostic build: ticks inside evaluator tile tasks */
-    AZD_CTR_TICKS_BATCH = 29,   /* diagnostic build: ticks from batch open to batch close, summed */
+    AZD_CTR_TICKS_BATCH = 29,   /* pool step, every build: 100 MHz ticks from batch taken to batch released, summed over the evaluator
+                                 * workgroups (bench.py's evaluator_weight_stream / us_per_batch read it); the asynchronous step fills it
+                                 * in the diagnostic build only */
     AZD_CTR_COUNT = 32
 };
 
@@ -414,6 +423,10 @@ int azd_engine_counters(azd_engine *e, uint64_t *out /* [AZD_CTR_COUNT] */);
  * read-modify-write of the agent's block was a dependent round trip on the wave's time): per-agent attribution under the pool
  * step is the diagnostic build's (make PROFILE=1, tools/slow_agents.py). */
 int azd_engine_agent_counters(azd_engine *e, uint64_t *out);
+/* 1 while every block of azd_engine_agent_counters holds its own agent's counts; 0 once a pool launch of the product build has
+ * run since the counters were last cleared (azd_engine_par_new): the blocks then hold what searcher waves counted and only their
+ * sums / maxima (azd_engine_counters) mean anything.  Load-balance tools must check this before reading per-agent values. */
+int azd_engine_agent_counters_per_agent(azd_engine *e);
 /* ms of GPU time spent in the tree kernels / evaluator since creation (HIP events
  * on the engine's stream; enabled by azd_engine_set_timing) */
 int azd_engine_set_timing(azd_engine *e, int enabled);

@@ -208,17 +208,28 @@ void lambda1_bracket(int n, double *lo, double *hi) {
 /* Round 4: once both ends of the bracket carry a value of the tree's characteristic polynomial phi_0 with the signs of a simple
  * crossing (phi_0(lo) < 0 < phi_0(hi)), the 32 trial points of a round go into a window around the secant's estimate of the root
  * -- half-width 8 (span / 2)^2, at least span / 1024 -- clipped to the bracket, instead of across the whole bracket.  The ends are
- * only ever replaced by trial points, so the bracket stays a bracket; 5.25 -> 3.6 rounds per node cost.  The device runs exactly
- * these operations (space_c21.inc:lambda1_impl), one IEEE f64 operation each. */
-double lambda1_sturm(const uint8_t *parents, int n, bool node_mode) {
+ * only ever replaced by trial points, so the bracket stays a bracket; 5.25 -> 3.6 rounds per node cost.
+ * Round 5: a window may MISS the root (all 32 points on one side of it: first == 0 or first == 32).  A near miss is harmless -- the
+ * end it moves lands beside the root and the next secant is good: half of all random trees have one and still finish in 3.6 rounds
+ * -- but with lambda_2 close to lambda_1 (the double brooms) |phi'' / phi'| is large, the estimate stays on one side and every
+ * round misses again: the bracket then creeps instead of shrinking.  The THIRD miss of a solve therefore switches the window off
+ * for the rest of it: the plain 33-section of [lo, hi] from there.  Every round that is not a miss shrinks the bracket 33-fold at
+ * least and there are at most three misses, so 15 rounds give what 12 plain rounds give (33^12 > 2^60).
+ * The device runs exactly these operations (space_c21.inc:lambda1_impl), one IEEE f64 operation each.
+ * windowed = false: the plain 33-section in every round (what rounds 1-3 ran; kept as the yardstick of the tests). */
+constexpr int LAMBDA1_MAX_MISSES = 3;
+double lambda1_sturm(const uint8_t *parents, int n, bool node_mode, bool windowed = true, int *rounds_out = nullptr) {
     double lo, hi;
     lambda1_bracket(n, &lo, &hi);
     double flo = 0.0, fhi = 0.0;
     bool have_lo = false, have_hi = false;
-    for (int round = 0; round < 12; ++round) {
+    int misses = windowed ? 0 : LAMBDA1_MAX_MISSES;
+    int round = 0;
+    for (; round < 12 + LAMBDA1_MAX_MISSES; ++round) {
         if (node_mode && (float)lo == (float)hi) break;
         double wlo = lo, whi = hi;
-        if (have_lo && have_hi && flo < 0.0 && fhi > 0.0) {
+        bool in_window = false;
+        if (misses < LAMBDA1_MAX_MISSES && have_lo && have_hi && flo < 0.0 && fhi > 0.0) {
             double span = hi - lo;
             double den = flo - fhi;
             double tt = flo / den;
@@ -233,6 +244,7 @@ double lambda1_sturm(const uint8_t *parents, int n, bool node_mode) {
                 double wa = c - d, wb = c + d;
                 if (wa > lo) wlo = wa;
                 if (wb < hi) whi = wb;
+                in_window = true;
             }
         }
         double ws = whi - wlo;
@@ -258,7 +270,9 @@ double lambda1_sturm(const uint8_t *parents, int n, bool node_mode) {
             fhi = ph[first];
             have_hi = true;
         }
+        if (in_window && (first == 0 || first == 32)) ++misses;
     }
+    if (rounds_out) *rounds_out = round;
     return hi;
 }
 
@@ -990,6 +1004,12 @@ int orc_all_possible_parent_modifications(const uint8_t *parents, int n, int *ou
 double orc_lambda1_jacobi(const uint8_t *parents, int n) { return lambda1_jacobi(parents, n); }
 double orc_lambda1_sturm(const uint8_t *parents, int n) { return lambda1_sturm(parents, n, false); }
 double orc_lambda1_node(const uint8_t *parents, int n) { return lambda1_sturm(parents, n, true); }
+double orc_lambda1_plain(const uint8_t *parents, int n, int node_mode) { return lambda1_sturm(parents, n, node_mode != 0, false); }
+int orc_lambda1_rounds(const uint8_t *parents, int n, int node_mode, int windowed) {
+    int r = 0;
+    lambda1_sturm(parents, n, node_mode != 0, windowed != 0, &r);
+    return r;
+}
 int orc_maximum_matching(const uint8_t *parents, int n, int *out_pairs) {
     std::vector<std::pair<int, int>> m;
     maximum_matching(parents, n, m);

@@ -50,6 +50,8 @@ int orc_all_possible_parent_modifications(const uint8_t *parents, int n, int *ou
 double orc_lambda1_jacobi(const uint8_t *parents, int n);  /* dense symmetric eigen-solve (what faer does) */
 double orc_lambda1_sturm(const uint8_t *parents, int n);   /* cost contract, full f64 bracket (ArgminData) */
 double orc_lambda1_node(const uint8_t *parents, int n);    /* cost contract, f32-exact early stop (node costs) */
+double orc_lambda1_plain(const uint8_t *parents, int n, int node_mode); /* the same bracket by plain 33-section only (yardstick) */
+int orc_lambda1_rounds(const uint8_t *parents, int n, int node_mode, int windowed); /* rounds the solve took */
 int orc_maximum_matching(const uint8_t *parents, int n, int *out_pairs); /* ordered_edge.rs:94-124 */
 float orc_c21_eval(int n, double lambda1, int matching_size);           /* 04-c21-tree.rs:58-74,98-102 */
 

@@ -50,6 +50,8 @@ def lib():
     sig("orc_lambda1_jacobi", C.c_double, vp, C.c_int)
     sig("orc_lambda1_sturm", C.c_double, vp, C.c_int)
     sig("orc_lambda1_node", C.c_double, vp, C.c_int)
+    sig("orc_lambda1_plain", C.c_double, vp, C.c_int, C.c_int)
+    sig("orc_lambda1_rounds", C.c_int, vp, C.c_int, C.c_int, C.c_int)
     sig("orc_maximum_matching", C.c_int, vp, C.c_int, vp)
     sig("orc_c21_eval", C.c_float, C.c_int, C.c_double, C.c_int)
     sig("orc_key4", C.c_uint64, C.c_uint64, C.c_uint64, C.c_uint64, C.c_uint64)

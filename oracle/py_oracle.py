@@ -123,7 +123,7 @@ def posdef(parents, n, x):
 
 
 def lambda1(parents, n, node_mode=False):
-    """cost contract for lambda_1: 33-section of [1, N], <= 12 rounds; node_mode stops as
+    """cost contract for lambda_1: 33-section of the bracket, <= 15 rounds; node_mode stops as
     soon as both bracket ends round to the same f32 (what the evaluation uses)"""
     # initial bracket: among the trees on n vertices the path has the smallest lambda_1, 2 cos(pi / (n + 1)), the star the
     # largest, sqrt(n - 1); both rounded to f32 and widened by 2^-20 (so that every restatement starts from the same doubles)
@@ -131,14 +131,19 @@ def lambda1(parents, n, node_mode=False):
     hi = float(F(math.sqrt(float(n - 1)))) + 2.0 ** -20
     # round 4: with phi_0 (the tree's characteristic polynomial) known at both ends and of the signs of a simple crossing, the
     # round's trial points go into a window around the secant's estimate of the root (half-width 8 (span / 2)^2, at least
-    # span / 1024, clipped to the bracket); the ends are only ever replaced by trial points, so the bracket stays a bracket
+    # span / 1024, clipped to the bracket); the ends are only ever replaced by trial points, so the bracket stays a bracket.
+    # round 5: the third window of a solve that misses the root (all 32 points on one side of it) switches the window off for the
+    # rest of the solve; every round that is no miss shrinks the bracket 33-fold at least, so 15 rounds give what 12 plain rounds
+    # give (33^12 > 2^60)
     flo = fhi = 0.0
     have_lo = have_hi = False
-    for _ in range(12):
+    misses = 0
+    for _ in range(15):
         if node_mode and F(lo) == F(hi):
             break
         wlo, whi = lo, hi
-        if have_lo and have_hi and flo < 0.0 and fhi > 0.0:
+        in_window = False
+        if misses < 3 and have_lo and have_hi and flo < 0.0 and fhi > 0.0:
             span = hi - lo
             den = flo - fhi
             tt = flo / den
@@ -156,6 +161,7 @@ def lambda1(parents, n, node_mode=False):
                     wlo = wa
                 if wb < hi:
                     whi = wb
+                in_window = True
         ws = whi - wlo
         w = ws / 33.0
         xs = [wlo + w * float(j + 1) for j in range(32)]
@@ -170,6 +176,8 @@ def lambda1(parents, n, node_mode=False):
             lo, flo, have_lo = xs[first - 1], ph[first - 1], True
         if first < 32:
             hi, fhi, have_hi = xs[first], ph[first], True
+        if in_window and (first == 0 or first == 32):
+            misses += 1
     return hi
 
 

@@ -129,3 +129,20 @@ def test_cpp_host_header_compiles_and_has_no_cpu_fallback(tmp_path):
         pytest.skip("a GPU is present: tests/test_gpu_examples.py runs the driver")
     r = subprocess.run([str(exe), "1", "1", "16"], capture_output=True, text=True, timeout=120)
     assert r.returncode == 1 and "no gfx950 device" in r.stderr, (r.returncode, r.stderr)
+
+
+def test_tree_capacities_names_the_record_format_limits():
+    """examples/c21_tree.py computed arc_capacity = 3 * episodes + 64, which azd_engine_create refuses above ~21.8 k episodes
+    (round-4 advisor finding): the helper clamps what is an estimate (arcs) and refuses, naming the argument, what is a need."""
+    import azdopt_amd as az
+    from azdopt_amd.optimizer import MAX_ARC_CAPACITY, MAX_NODE_CAPACITY, MAX_PREDICTION_CAPACITY
+    assert az.tree_capacities(800, 76) == dict(node_capacity=4096, arc_capacity=8192, prediction_capacity=(801 * 76 + 128))
+    big = az.tree_capacities(30000, 20)
+    assert big["arc_capacity"] == MAX_ARC_CAPACITY and big["node_capacity"] == 60064 <= MAX_NODE_CAPACITY
+    assert big["prediction_capacity"] <= MAX_PREDICTION_CAPACITY
+    with pytest.raises(ValueError, match="node_capacity"):
+        az.tree_capacities(40000, 8)
+    with pytest.raises(ValueError, match="prediction_capacity"):
+        az.tree_capacities(20000, 76)
+    hdr = open(os.path.join(ROOT, "include", "azdopt_amd.h")).read()
+    assert "#define AZD_MAX_NODE_CAPACITY 65536" in hdr and "#define AZD_MAX_ARC_CAPACITY 65535" in hdr

@@ -488,3 +488,31 @@ def test_reference_cost_vectors_on_the_device(az, orc):
                 assert abs(lam[0] - lam_want) < 1e-6
             fn = orc.lib().orc_lambda1_sturm if full else orc.lib().orc_lambda1_node
             assert lam[0] == fn(_lib.ptr(p), n)
+
+
+def test_near_degenerate_trees_on_the_device(az, orc):
+    """Round-4 advisor finding (high): the double brooms, where lambda_2 sits beside lambda_1 and the secant window of the
+    lambda_1 bracket never caught the root.  Every split of the two-hub family (tests/test_oracle_golden.py:double_brooms,
+    N = 6 .. AZD_C21_MAX_N) through the device's cost function in both modes: bit for bit the oracle's f64, and within 1e-12 of
+    LAPACK in full mode."""
+    import ctypes as C
+    from azdopt_amd import _lib
+    from test_oracle_golden import double_brooms, _lapack_lambda1
+    by_n = {}
+    for parents in double_brooms():
+        by_n.setdefault(len(parents), []).append(parents)
+    checked = 0
+    for n, trees in sorted(by_n.items()):
+        p = np.array(trees, np.uint8)
+        for full in (0, 1):
+            lam, mu, ms = np.zeros(len(trees), np.float64), np.zeros(len(trees), np.int32), C.c_float()
+            _lib.check(az.lib().azd_debug_probe_cost(0, _lib.ptr(p), n, len(trees), 1, full, _lib.ptr(lam), _lib.ptr(mu), C.byref(ms)), "probe_cost")
+            fn = orc.lib().orc_lambda1_sturm if full else orc.lib().orc_lambda1_node
+            for i, parents in enumerate(trees):
+                row = np.ascontiguousarray(p[i])
+                assert lam[i] == fn(_lib.ptr(row), n), (n, parents, full)
+                assert mu[i] == orc.lib().orc_maximum_matching(_lib.ptr(row), n, None)
+                if full:
+                    assert abs(lam[i] - _lapack_lambda1(parents)) < 1e-12 * n
+                checked += 1
+    assert checked > 3000

@@ -573,3 +573,39 @@ def test_run_ahead_window_survives_an_aborted_launch(az, monkeypatch):
     form, why = opt.step_form()
     assert form == "async" and why.startswith("pool step aborted"), (form, why)
     same_engines(opt, sum(got), ref, imp_ref, range(B))
+
+
+def test_agent_counters_say_when_they_are_not_per_agent(az):
+    """Round-4 advisor finding: under the pool step of the product build a searcher wave adds its counts to ONE block when it
+    leaves the launch, so azd_engine_agent_counters is no per-agent table there.  The engine says so
+    (azd_engine_agent_counters_per_agent), the host mirror refuses to hand the blocks out as per-agent values, and the sums / maxima
+    of the blocks are pinned equal to the asynchronous form's, whose blocks ARE per agent."""
+    n, B, seed, calls = 19, 320, 4, 60
+    space = az.ROTModifyParentsOnce(n)
+    roots = space.generate_roots(seed, B)
+    pair = []
+    for pool in (True, False):
+        o = az.NablaOptimizer.par_new(space, roots, az.ActionModel(B, space.STATE_DIM, space.ACTION_DIM, hidden=(256, 256, 256), seed=seed), B, pool_step=pool)
+        assert o._L.azd_engine_agent_counters_per_agent(o._h) == 1
+        o.par_roll_out_episodes(TOL_REF, n_calls=calls)
+        pair.append(o)
+    pool, asy = pair
+    assert pool.step_form()[0] == "pool" and asy.step_form()[0] == "async"
+    per_agent = asy.agent_counters()
+    assert asy._L.azd_engine_agent_counters_per_agent(asy._h) == 1
+    assert per_agent["EXPANSIONS"].max() <= calls and per_agent["EXPANSIONS"].sum() == asy.counters()["EXPANSIONS"]
+    if "prof" not in az._lib.LIB_PATH:  # (the diagnostic build keeps per-agent blocks under the pool step too)
+        assert pool._L.azd_engine_agent_counters_per_agent(pool._h) == 0
+        with pytest.raises(RuntimeError, match="searcher waves"):
+            pool.agent_counters()
+    blocks = pool.agent_counters(allow_wave_blocks=True)
+    cp, ca = pool.counters(), asy.counters()
+    for k in MAIN_CTRS:
+        assert cp[k] == ca[k], k
+        if k not in ("MAX_FRONTIER", "MAX_DEPTH"):
+            assert int(blocks[k].sum()) == cp[k], k
+    # a fresh par_new clears the counters and with them the attribution flag
+    from azdopt_amd import _lib
+    parents, permitted = pool._roots(*roots)
+    _lib.check(pool._L.azd_engine_par_new(pool._h, _lib.ptr(parents), _lib.ptr(permitted)), "par_new")
+    assert pool._L.azd_engine_agent_counters_per_agent(pool._h) == 1

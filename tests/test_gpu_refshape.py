@@ -112,3 +112,25 @@ def test_prediction_capacity_overflow_is_reported(az, persistent, async_step):
         opt.par_roll_out_episodes(TOL_REF, n_calls=200)
     assert ei.value.status == 4  # AZD_ERR_CAPACITY
     assert opt.counters()["FAILED"] > 0
+
+
+def test_capacities_at_the_record_format_limits(az):
+    """Round-4 advisor finding (medium): the packed prediction / node records limit a tree to 65536 nodes, 65535 arcs and 2^20
+    predictions (the reference's petgraph indices are u32).  Creation AT the limits succeeds and a short run works; one beyond
+    each limit is refused with an error that names the argument -- never accepted and corrupted later."""
+    from azdopt_amd.optimizer import MAX_ARC_CAPACITY, MAX_NODE_CAPACITY, MAX_PREDICTION_CAPACITY
+    space = az.ROTModifyParentsOnce(19)
+    B = 4
+    roots = space.generate_roots(0, B)
+    model = az.HashStreamModel(space.STATE_DIM, space.ACTION_DIM, 0)
+    opt = az.NablaOptimizer.par_new(space, roots, model, B, node_capacity=MAX_NODE_CAPACITY, arc_capacity=MAX_ARC_CAPACITY,
+                                    prediction_capacity=MAX_PREDICTION_CAPACITY)
+    opt.par_roll_out_episodes(TOL_REF, n_calls=20)
+    ref = az.NablaOptimizer.par_new(space, roots, az.HashStreamModel(space.STATE_DIM, space.ACTION_DIM, 0), B)
+    ref.par_roll_out_episodes(TOL_REF, n_calls=20)
+    assert opt.counters()["EXPANSIONS"] == ref.counters()["EXPANSIONS"] > 0 and opt.argmin_data().eval == ref.argmin_data().eval
+    for kw, name in ((dict(node_capacity=MAX_NODE_CAPACITY + 1), "node_capacity"), (dict(arc_capacity=MAX_ARC_CAPACITY + 1), "arc_capacity"),
+                     (dict(prediction_capacity=MAX_PREDICTION_CAPACITY + 1), "prediction_capacity")):
+        with pytest.raises(az.AzdError) as ei:
+            az.NablaOptimizer.par_new(space, roots, model, B, **kw)
+        assert ei.value.status == 1 and name in str(ei.value), str(ei.value)  # AZD_ERR_INVALID_ARGUMENT

@@ -38,12 +38,17 @@ def main():
     files = sys.argv[1:] or sorted(glob.glob(os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "azdopt_amd", "csrc", "build", "*.o")))
     bad = []
     n_kernels = 0
+    seen = set()
     with tempfile.TemporaryDirectory() as tmp:
         for f in files:
             base = os.path.basename(f)[:-2]
             co = code_object(f, tmp)
             if not co:
+                # host-only objects carry no device code; a tree / step / space unit that cannot be read is a FAILED check, not a pass
+                if base in TREE_TUS:
+                    bad.append("%s: no gfx950 code object could be extracted (llvm-objcopy / clang-offload-bundler missing, or another offload arch): NOT CHECKED" % base)
                 continue
+            seen.add(base)
             syms = subprocess.run([LLVM + "/llvm-readelf", "-sW", co], capture_output=True, text=True).stdout.splitlines()
             funcs = {l.split()[-1] for l in syms if " FUNC " in l}
             kernels = {l.split()[-1][:-3] for l in syms if l.rstrip().endswith(".kd")}
@@ -60,6 +65,12 @@ def main():
                     bad.append("%s: private segment %d B > %d: %s" % (base, scratch, SCRATCH_BUDGET, demangle(name)[:140]))
                 if dyn == "true":
                     bad.append("%s: dynamic stack: %s" % (base, demangle(name)[:140]))
+    if not sys.argv[1:]:  # the default run is the build's guard: every unit it exists for must have been looked at
+        for tu in TREE_TUS:
+            if tu not in seen and not any(tu in b for b in bad):
+                bad.append("%s: object missing from the build directory: NOT CHECKED" % tu)
+    if n_kernels == 0:
+        bad.append("no kernel found in %d object(s): nothing was checked" % len(files))
     for b in bad:
         print("check_kernels:", b)
     print("check_kernels: %d kernels in %d objects, %d violation(s)" % (n_kernels, len(files), len(bad)))
