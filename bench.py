@@ -17,6 +17,9 @@ built (A: the reference's own run shape, B = 512 with the 512-1024-512 MLP; C: 8
 evaluator storage; D: the Ramsey space, 8192 agents per GPU).  N > 1: agents shard by global id (weak
 scaling, no data-path collective); the training triple is all-gathered over RCCL once per epoch so that
 every rank takes the identical optimiser step (azdopt_amd.parallel.ShardedOptimizer).
+Launching: under torch.distributed.run (RANK / WORLD_SIZE set) a process IS one rank; `python bench.py --gpus N` on its own
+starts its N ranks itself, as child processes, before it has made any GPU call (self_launch) and passes rank 0's line through.
+`config.baseline_config_note` says which BASELINE.json configuration the run is (C is quoted at 8 GPUs, D at 4).
 
 What the timed window holds is reported, not assumed: `config.workload` is built from what ran, and
 `epoch_boundaries_in_timed_region` counts the par_update_model + root policy + par_reset_trees sequences
@@ -191,6 +194,68 @@ def best_cost_run(az, wl, hidden, B, mlp_dtype, max_epochs, goal=5.2):
     return out
 
 
+# BASELINE.json configs[] are quoted at fixed GPU counts: which of them a run IS, and which it only shares the per-GPU shape with
+BASELINE_GPUS = {"A": (0, None), "B": (1, 1), "C": (2, 8), "D": (3, 4), "E": (4, 8), "E612": (4, 8)}
+
+
+def baseline_note(cfg, world, agents_total):
+    if cfg is None:
+        return "not a BASELINE.json configuration (custom workload / agents / storage)"
+    idx, gpus = BASELINE_GPUS[cfg]
+    if gpus is None:
+        return "BASELINE.json configs[0]'s shape (the reference's own run, 512 agents) on %d GPU(s)" % world
+    if world == gpus:
+        return "BASELINE.json configs[%d] exactly: %d agents over %d GPU(s)" % (idx, agents_total, world)
+    return ("the per-GPU shape of BASELINE.json configs[%d] (quoted at %d GPUs) on %d GPU(s): %d agents in all -- the driver's 1/2/4/8 curve "
+            "keeps ONE per-GPU workload (weak scaling); `--gpus %d --config %s` is that configuration itself" % (idx, gpus, world, agents_total, gpus, cfg))
+
+
+def self_launch(n):
+    """`python bench.py --gpus N` with no launcher around it (WORLD_SIZE unset): start the N ranks as child processes of this one --
+    RANK / LOCAL_RANK / WORLD_SIZE / MASTER_ADDR / MASTER_PORT set as torch.distributed.run sets them -- BEFORE this process has
+    made any GPU call (it never does: a process that has touched the GPU must not be replaced or forked on this pool), pass
+    rank 0's stdout through (the one JSON line), and exit with the first non-zero status of any rank (the others are stopped:
+    a rank that lost its peers would otherwise sit in a collective until its time-out)."""
+    import socket
+    import subprocess
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    import tempfile
+    procs = []
+    out0 = tempfile.TemporaryFile(mode="w+")  # rank 0's stdout (a file, not a pipe: nothing to drain while the ranks run)
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=out0 if r == 0 else subprocess.DEVNULL))
+    rc = 0
+    try:
+        live = set(range(n))
+        while live:
+            for r in sorted(live):
+                code = procs[r].poll()
+                if code is None:
+                    continue
+                live.discard(r)
+                if code != 0 and rc == 0:
+                    rc = code
+                    print("bench: rank %d exited with status %d; stopping the other ranks" % (r, code), file=sys.stderr)
+                    for q in live:
+                        procs[q].terminate()
+            time.sleep(0.05)
+    finally:
+        for pr in procs:
+            if pr.poll() is None:
+                pr.kill()
+    out0.seek(0)
+    out0 = out0.read()
+    sys.stdout.write(out0)
+    sys.stdout.flush()
+    raise SystemExit(rc)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -233,10 +298,27 @@ def main():
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        self_launch(args.gpus)  # (does not return)
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus:
-        raise SystemExit("--gpus %d but WORLD_SIZE is %d: launch with torch.distributed.run --nproc-per-node %d"
-                         % (args.gpus, world, args.gpus))
+        raise SystemExit("--gpus %d but WORLD_SIZE is %d: launch with torch.distributed.run --nproc-per-node %d, or unset WORLD_SIZE and "
+                         "let bench.py start its own ranks" % (args.gpus, world, args.gpus))
+    if os.environ.get("AZD_BENCH_SPAWN_PROBE") == "1":
+        # test hook of the launch path alone (tests/test_parallel_gloo.py, no GPU): rendezvous over gloo with the environment the
+        # launcher set, one all-reduce, rank 0 prints what it saw
+        import torch
+        import torch.distributed as dist
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+        t = torch.tensor([float(rank + 1)], dtype=torch.float64)
+        dist.all_reduce(t)
+        if os.environ.get("AZD_BENCH_SPAWN_PROBE_FAIL") == str(rank):
+            raise SystemExit(7)
+        dist.barrier()
+        if rank == 0:
+            print(json.dumps({"metric": "spawn_probe", "world": world, "sum": float(t[0]), "gpus": args.gpus, "config": args.config}), flush=True)
+        dist.destroy_process_group()
+        return
     import torch
     import torch.distributed as dist
     # rehearsal on a one-GPU box (never used by the driver): AZD_BENCH_REHEARSE=1 puts every rank on
@@ -453,6 +535,7 @@ def main():
                                       AGENTS_PER_GPU, "fp32" if mlp_dtype == "f32" else "bf16-storage", dims_txt,
                                       str(TOL[0]).replace(" ", ""), TOL[1], window),
                        "baseline_config": args.config or ("B" if (wl_name, AGENTS_PER_GPU, mlp_dtype) == CONFIGS["B"] else None),
+                       "baseline_config_note": baseline_note(args.config or ("B" if (wl_name, AGENTS_PER_GPU, mlp_dtype) == CONFIGS["B"] else None), world, B_total),
                        "agents_total": B_total, "parallelism": f"agents sharded x{world}"},
             "world": world, "per_rank_expansions_per_s": per_rank_rates, "replicas_identical": replicas_ok,
             "epoch_exchange": None if world == 1 else {

@@ -222,3 +222,35 @@ def test_sharded_optimizer_equals_one_optimizer_gloo(orc, world):
     assert np.array_equal(np.concatenate([r[5] for r in res]), sv)                 # same trees => same current states
     assert min(r[6] for r in res) == float(one.e.argmin()["eval"])
     assert losses[0] > 0 and np.isfinite(losses).all()
+
+
+def _bench_cmd(*args, **env):
+    import subprocess
+    e = dict(os.environ)
+    e.pop("WORLD_SIZE", None)
+    e.pop("RANK", None)
+    e.update(env)
+    return subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), *args], capture_output=True, text=True, timeout=300, cwd=ROOT, env=e)
+
+
+def test_bench_launches_its_own_ranks():
+    """Round-4 verdict, item 3: `python bench.py --gpus N` with no launcher around it starts its N ranks itself (before any GPU call),
+    hands them the rendezvous environment torch.distributed.run would, prints rank 0's ONE line and returns the ranks' status.
+    The launch path alone, over gloo on CPUs (AZD_BENCH_SPAWN_PROBE: the ranks rendezvous, all-reduce, rank 0 reports)."""
+    import json
+    r = _bench_cmd("--gpus", "2", "--config", "C", "--steps", "20", "--warmup", "5", AZD_BENCH_SPAWN_PROBE="1")
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [x for x in r.stdout.splitlines() if x.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    j = json.loads(lines[0])
+    assert j == {"metric": "spawn_probe", "world": 2, "sum": 3.0, "gpus": 2, "config": "C"}
+    # four ranks, one of which fails: the job's status is that rank's, and nobody is left behind in a collective
+    r = _bench_cmd("--gpus", "4", AZD_BENCH_SPAWN_PROBE="1", AZD_BENCH_SPAWN_PROBE_FAIL="2")
+    assert r.returncode == 7 and "rank 2 exited with status 7" in r.stderr
+    assert not [x for x in r.stdout.splitlines() if x.startswith("{")]
+
+
+def test_bench_under_a_launcher_still_checks_the_world_size():
+    r = _bench_cmd("--gpus", "2", AZD_BENCH_SPAWN_PROBE="1", WORLD_SIZE="1", RANK="0")
+    # (WORLD_SIZE set: the launcher's job; a mismatch is refused as before)
+    assert r.returncode != 0 and "WORLD_SIZE" in (r.stderr + r.stdout)
