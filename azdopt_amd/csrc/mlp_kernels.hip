@@ -832,7 +832,9 @@ static int mlp_init(MlpEvaluator *m, uint64_t seed) {
         m->p_off[(size_t)l] = m->n_packed;
         m->n_packed += (int64_t)((m->dims[(size_t)l + 1] + 15) / 16) * ((m->dims[(size_t)l] + 15) / 16) * 256;
     }
-    AZD_HIP(hipMalloc(&m->d_wpk, (size_t)m->n_packed * 4));
+    // + 8 KB: a ragged last group of the pool step's tile task requests up to 7 k-steps past its tile (tile_task_asm.inc); never used
+    AZD_HIP(hipMalloc(&m->d_wpk, (size_t)m->n_packed * 4 + 8192));
+    AZD_HIP(hipMemset(m->d_wpk, 0, (size_t)m->n_packed * 4 + 8192));
     {
         size_t big = 0;
         for (int l = 0; l < m->L; ++l) {

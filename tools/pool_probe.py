@@ -31,3 +31,7 @@ if d["EVAL_BATCHES"]:
     print("  batches %d rows %d rows/batch %.2f tiles %d  us/batch %.1f" % (d["EVAL_BATCHES"], d["EVAL_ROWS"], d["EVAL_ROWS"] / d["EVAL_BATCHES"], d["EVAL_TILES"], d["TICKS_BATCH"] / 100.0 / d["EVAL_BATCHES"]))
     print("  per batch: rows-in %.1f us, layers %.1f us, out+release %.1f us" % (d["TICKS_TILE_SETUP"] / 100.0 / d["EVAL_BATCHES"], d["TICKS_TILE_KLOOP"] / 100.0 / d["EVAL_BATCHES"],
           (d["TICKS_BATCH"] - d["TICKS_TILE_SETUP"] - d["TICKS_TILE_KLOOP"]) / 100.0 / d["EVAL_BATCHES"]))
+    if d.get("EVAL_LAYER_CLOCKS") and d["TICKS_TILE_KLOOP"]:
+        ghz = d["EVAL_LAYER_CLOCKS"] / (d["TICKS_TILE_KLOOP"] * 10.0)
+        mfma = sum(((b + 15) // 16) * ((a + 15) // 16) * 4 for a, b in zip((space.STATE_DIM,) + hidden, hidden + (space.ACTION_DIM,))) * 32 / 4
+        print("  evaluator CUs' clock in the layers: %.2f GHz; fp32 MFMA issue of a batch: %d clocks per SIMD = %.1f us at that clock" % (ghz, mfma, mfma / ghz / 1e3))
