@@ -763,6 +763,12 @@ int azd_engine_create(azd_engine **out, const azd_engine_config *cfg, azd_evalua
     TRY(e->alloc(&a.n_arcs, B));
     TRY(e->alloc(&a.n_preds, B));
     TRY(e->alloc(&a.flags, B));
+    a.fr_lds = (uint32_t)azd::FRONTIER_CAP;
+    if (const char *v = getenv("AZD_DEBUG_FRONTIER_LDS")) { // test hook: a smaller LDS share, so that small trees reach the spill arena
+        const int k = atoi(v);
+        if (k >= 64 && k <= azd::FRONTIER_CAP && k % 64 == 0) a.fr_lds = (uint32_t)k;
+    }
+    TRY(e->alloc(&a.fr_spill, B * 4 * a.node_cap)); // cascade frontier levels beyond the LDS's FRONTIER_CAP entries: (node, x) x node_cap x 2 levels
     TRY(e->alloc(&a.cand_c, B));
     TRY(e->alloc(&a.cand_node, B));
     TRY(e->alloc(&a.counters, B * azd::NUM_COUNTERS));
@@ -1063,8 +1069,13 @@ static int dense_pool_run(azd_engine *e, const azd::TolTable &t, int n_calls, bo
     // wavefronts per searcher workgroup: 16, or as many as the LDS holds (roots of more than 640 slots: 12 -- a wave's block and its
     // selection scratch are 12 KB there)
     int waves = 16;
-    if (const char *env = getenv("AZD_DENSE_POOL_WAVES")) waves = atoi(env);
-    waves = waves < 1 ? 1 : waves > 16 ? 16 : waves;
+    if (const char *env = getenv("AZD_DENSE_POOL_WAVES")) {
+        waves = atoi(env);
+        if (waves < 4 || waves > 16) { // (round-4 verdict, 7c: a knob out of range is refused, not silently bent)
+            azd::g_last_error = "AZD_DENSE_POOL_WAVES must be 4..16 (wavefronts per searcher workgroup of the dense-graph pool step)";
+            return AZD_ERR_INVALID_ARGUMENT;
+        }
+    }
     while (waves > 4 && !azd::dense_pool_plan(a, waves, &dyn_stride, &dyn_bytes, &why)) waves -= 1;
     azd::FusedEval fe;
     const bool hashed = e->ev->fused_desc(&fe) && fe.kind == 4; // the test harness' fixed prediction stream, served like a model's rows
@@ -1083,6 +1094,20 @@ static int dense_pool_run(azd_engine *e, const azd::TolTable &t, int n_calls, bo
     int n_search = (2 * a.B + waves - 1) / waves;
     if (n_search > e->n_cus * 8 / waves) n_search = e->n_cus * 8 / waves;
     if (const char *env = getenv("AZD_DENSE_POOL_SEARCH_WGS")) n_search = atoi(env) > 0 ? atoi(env) : n_search;
+    // The evaluator of this form is a stream of GEMM LAUNCHES beside the searchers' persistent kernel: they run only where a CU has
+    // LDS and registers left, and a searcher workgroup (1024 threads' worth of LDS blocks) leaves none.  A setting of the two knobs
+    // that lets the searchers cover more than three quarters of the CUs used to be accepted and then cost a 4-s wait bound, an
+    // abort and the engine's demotion to the launch-per-phase form (gpurun_out/ew.txt, round 4): refused up front instead.
+    // (workgroups, not wave slots: the dispatcher deals one workgroup to every CU before it doubles up, so 256 workgroups of 8 waves
+    // sit on 256 CUs although two would fit one)
+    if (per_cu >= 1 && (getenv("AZD_DENSE_POOL_SEARCH_WGS") || getenv("AZD_DENSE_POOL_WAVES")) && n_search > e->n_cus - e->n_cus / 4) {
+        static thread_local char msg[256];
+        snprintf(msg, sizeof msg, "AZD_DENSE_POOL_SEARCH_WGS / AZD_DENSE_POOL_WAVES: %d searcher workgroups of %d waves would sit on %d of %d CUs; "
+                 "the evaluator's GEMM launches need at least a quarter of the chip free (at most %d workgroups)", n_search, waves,
+                 n_search < e->n_cus ? n_search : e->n_cus, e->n_cus, e->n_cus - e->n_cus / 4);
+        azd::g_last_error = msg;
+        return AZD_ERR_INVALID_ARGUMENT;
+    }
     if (per_cu < 1 || n_search > e->n_cus * per_cu * 7 / 8) n_search = per_cu < 1 ? 0 : e->n_cus * per_cu * 7 / 8;
     if (n_search < 1) {
         e->step_reason = "dense-graph space: the device holds no searcher workgroup of the pool step";

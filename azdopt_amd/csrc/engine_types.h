@@ -24,7 +24,7 @@ constexpr int PATH_SET = 0, PATH_SEQUENCE = 1;   // = AZD_PATH_*
 constexpr int SPACE_C21 = 1, SPACE_RAMSEY = 2, SPACE_DENSE = 3; // = AZD_SPACE_* of include/azdopt_amd.h
 constexpr int PRED_CHUNKS = 2;               // a node holds at most 64*PRED_CHUNKS legal actions
 constexpr int MAX_NODE_ACTIONS = 64 * PRED_CHUNKS;
-constexpr int FRONTIER_CAP = 256;            // LDS-staged cascade frontier per tree
+constexpr int FRONTIER_CAP = 256;            // LDS-staged cascade frontier per tree (a level's entries beyond it go to Arenas::fr_spill)
 constexpr int PATH_STACK = 32;               // nodes of the current path kept per agent, root first (deeper levels: not kept)
 constexpr int MAX_TOL = 32;
 constexpr int NUM_COUNTERS = 32; // 0..15 public counters, 16..24 phase ticks (AZD_PHASE_PROFILE builds), 25..27 evaluator service
@@ -159,6 +159,8 @@ struct Arenas {
     uint32_t *state_pos;
     uint32_t *n_nodes, *n_arcs, *n_preds;
     uint32_t *flags;
+    uint32_t fr_lds;        // entries of a frontier level kept in LDS: FRONTIER_CAP (test hook AZD_DEBUG_FRONTIER_LDS: 64, 128 or 192)
+    uint32_t *fr_spill;     // [B][2][node_cap][2] cascade frontier entries beyond the FRONTIER_CAP the wave's LDS holds: (node, x) per level
     float *cand_c;          // first-min eval over nodes created since the last argmin inspection
     uint32_t *cand_node;
     unsigned long long *counters; // [B][NUM_COUNTERS]

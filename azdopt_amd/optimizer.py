@@ -61,13 +61,13 @@ def tree_capacities(episodes, max_actions_per_node):
     records limit a tree to 65536 nodes, 65535 arcs and 2^20 predictions (the reference's u32 indices do not): an epoch beyond them
     is refused HERE, naming the argument, rather than by azd_engine_create."""
     node = max(4096, 2 * episodes + 64)  # one expansion per call, plus the terminal nodes met on the way
-    arc = max(8192, 3 * episodes + 64)
+    arc = max(8192, 8 * episodes + 64)   # the new arc plus the transpositions of the re-descents (r44's dense DAGs: 5-6 per call)
     pred = max(32768, (episodes + 1) * max_actions_per_node + 128)
     for name, want, limit in (("node_capacity", node, MAX_NODE_CAPACITY), ("prediction_capacity", pred, MAX_PREDICTION_CAPACITY)):
         if want > limit:
             raise ValueError(f"{episodes} episodes per epoch need {name} = {want}, beyond the record format's {limit}: "
                              f"use at most {(limit - 64) // 2 if name == 'node_capacity' else (limit - 128) // max_actions_per_node - 1} episodes per epoch")
-    # arcs: 3 per call is a generous estimate, not a need; an epoch that does run out stops its agent with AZD_ERR_CAPACITY
+    # arcs: 8 per call is a generous estimate, not a need; an epoch that does run out stops its agent with AZD_ERR_CAPACITY
     return dict(node_capacity=node, arc_capacity=min(arc, MAX_ARC_CAPACITY), prediction_capacity=pred)
 
 

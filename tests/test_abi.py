@@ -137,6 +137,7 @@ def test_tree_capacities_names_the_record_format_limits():
     import azdopt_amd as az
     from azdopt_amd.optimizer import MAX_ARC_CAPACITY, MAX_NODE_CAPACITY, MAX_PREDICTION_CAPACITY
     assert az.tree_capacities(800, 76) == dict(node_capacity=4096, arc_capacity=8192, prediction_capacity=(801 * 76 + 128))
+    assert az.tree_capacities(3200, 68)["arc_capacity"] == 8 * 3200 + 64  # the r44 driver's epoch (02-r44.rs:126)
     big = az.tree_capacities(30000, 20)
     assert big["arc_capacity"] == MAX_ARC_CAPACITY and big["node_capacity"] == 60064 <= MAX_NODE_CAPACITY
     assert big["prediction_capacity"] <= MAX_PREDICTION_CAPACITY

@@ -351,3 +351,23 @@ def test_hipgraph_replay_of_the_per_call_form_equals_launch_by_launch(az, monkey
     o = az.NablaOptimizer.par_new(sp, sp.generate_roots(1, 64), m, 64, persistent=False)
     o.par_roll_out_episodes(([200, 50, 50], 25), n_calls=10)
     assert o.step_form()[0] == "per_call_graph"
+
+
+@pytest.mark.parametrize("env", [{"AZD_DENSE_POOL_WAVES": "8", "AZD_DENSE_POOL_SEARCH_WGS": "256"}, {"AZD_DENSE_POOL_WAVES": "2"}, {"AZD_DENSE_POOL_SEARCH_WGS": "250"}])
+def test_dense_pool_knobs_that_leave_no_room_for_the_gemm_launches_are_refused(az, monkeypatch, env):
+    """Round-4 verdict, 7c: AZD_DENSE_POOL_WAVES = 8 / 6 used to be accepted, let the searcher workgroups cover the chip, and cost a
+    4-s wait bound, an abort and the engine's demotion to the launch-per-phase form.  A setting that would leave the evaluator's
+    GEMM launches less than a quarter of the CUs (or a wave count outside 4..16) is now refused before anything is launched."""
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    n, B, seed = 50, 640, 5
+    space = az.DenseGraphSpace(n, 0.1, max_slots=128)
+    model = az.ActionModel(B, space.STATE_DIM, space.ACTION_DIM, hidden=(512, 512, 512), seed=seed, dtype="bf16")
+    o = az.NablaOptimizer.par_new(space, space.generate_roots(seed, B), model, B, prediction_capacity=131072)
+    with pytest.raises(az.AzdError) as ei:
+        o.par_roll_out_episodes(([200, 50, 50], 25), n_calls=5)
+    assert ei.value.status == 1 and "AZD_DENSE_POOL" in str(ei.value)  # AZD_ERR_INVALID_ARGUMENT, naming the knob
+    for k in env:
+        monkeypatch.delenv(k)
+    o.par_roll_out_episodes(([200, 50, 50], 25), n_calls=5)  # (the engine is not demoted by the refusal)
+    assert o.step_form()[0] == "pool"

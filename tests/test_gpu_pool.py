@@ -378,6 +378,29 @@ def test_product_pool_kernel_with_bf16_storage_over_a_whole_epoch_against_the_or
         assert_tree_equal(opt.get_tree(i), oe.export_tree(i), f"agent {i}")
 
 
+def test_config_c_at_its_real_shape_against_the_oracle(az, orc):
+    """BASELINE configs[2] as one case (round-4 verdict, 7a): 8192 agents per GPU, bf16 weight / activation storage, 200 calls in ONE
+    launch of the product kernel -- more agents than searcher waves, 32-row evaluator batches, early posts by the agents behind the
+    mean -- against the oracle fed with the in-kernel evaluator's rows of its own states: global counters, improvement count, every
+    state vector, the argmin, and every 61st tree record by record."""
+    n, B, seed, calls = 19, 8192, 41, 200
+    space = az.ROTModifyParentsOnce(n)
+    roots = space.generate_roots(seed, B)
+    model = az.ActionModel(B, space.STATE_DIM, space.ACTION_DIM, hidden=(256, 256, 256), seed=seed, dtype="bf16")
+    opt = az.NablaOptimizer.par_new(space, roots, model, B, pool_step=True)
+    oe = orc.Engine(n, B, threads=16)
+    oe.new_begin(*roots)
+    oe.new_end(opt.predictions())
+    _follow_with_the_oracle(opt, oe, TOL_REF, calls)
+    assert opt.step_form() == ("pool", "")
+    c = opt.counters()
+    assert c["EXPANSIONS"] > 150 * B and c["EVAL_ROWS"] == c["EXPANSIONS"] and c["EVAL_ROWS"] / c["EVAL_BATCHES"] > 16  # 32-row batches ran
+    ag, ao = opt.argmin_data(), oe.argmin()
+    assert ag.eval == ao["eval"] and np.array_equal(ag.state["parents"], ao["parents"])
+    for i in range(0, B, 61):
+        assert_tree_equal(opt.get_tree(i), oe.export_tree(i), f"agent {i}")
+
+
 def test_asynchronous_step_with_the_real_model_in_one_launch_against_the_oracle(az, orc):
     """k_async (agents bound to waves, the evaluator served by the waiting waves of the workgroup: the default below 256 agents)
     with the real model, 300 calls in one launch, against the oracle: its tile task is the pool step's, so the same rows feed it"""

@@ -131,6 +131,36 @@ def test_ramsey_wide_cascades_with_mlp_predictions(az, orc):
         assert_tree_equal(opt.get_tree(i), oe.export_tree(i), f"agent {i}")
 
 
+def test_ramsey_cascade_levels_wider_than_the_lds_frontier(az, orc, monkeypatch):
+    """The reference's frontier is a BTreeMap (empty_transitions.rs:62-86): unbounded.  Until round 5 a level of more than 256
+    distinct ancestors -- what the reference's own r44 run length of 3200 episodes per epoch produces (02-r44.rs:126; 24 of its
+    512 agents in the first epoch) -- stopped the agent with FLAG_FRONTIER_CAP.  A level's entries beyond the wave's LDS share now
+    go to the agent's slice of a device arena.  Here the LDS share is lowered to 64 entries (test hook), so that the levels of 100+
+    ancestors this search reaches run through the arena: every tree and counter against the oracle."""
+    monkeypatch.setenv("AZD_DEBUG_FRONTIER_LDS", "64")
+    n, sizes, B, seed, calls = 17, [4, 4], 48, 3, 800
+    tol = ([200, 200, 100, 100, 50, 50, 25, 25], 10)
+    space = az.RamseySpaceNoEdgeRecolor(n, sizes)
+    model = az.ActionModel(B, space.STATE_DIM, space.ACTION_DIM, hidden=(256, 256, 256), seed=seed)
+    colors, permitted = space.generate_roots(seed, B)
+    opt = az.NablaOptimizer.par_new(space, (colors, permitted), model, B)
+    oe = orc.Engine(n, B, threads=8, ramsey=(sizes, [1.0, 1.0]))
+    oe.new_begin(colors, permitted)
+    oe.new_end(opt.predictions())
+    for s in range(calls):
+        opt.par_roll_out_episodes(tol)
+        oe.rollout_begin(*tol)
+        oe.rollout_end(opt.predictions())
+    cg, co = opt.counters(), oe.counters()
+    assert cg["FAILED"] == 0, cg
+    for k in MAIN_CTRS:
+        assert cg[k] == co[k], (k, cg[k], co[k])
+    assert cg["MAX_FRONTIER"] > 64 + 16, cg["MAX_FRONTIER"]  # well beyond the lowered LDS share: the arena held part of a level
+    assert np.array_equal(opt.state_vecs(), oe.state_vecs())
+    for i in range(B):
+        assert_tree_equal(opt.get_tree(i), oe.export_tree(i), f"agent {i}")
+
+
 @pytest.mark.parametrize("persistent", [True, False])
 def test_ramsey_k4_and_weights_all_branches(az, orc, persistent):
     c = run_ramsey_parity(az, orc, 9, [4, 3], [1.0, 0.5], B=48, kmin=3, kmax=8, tol=([8, 4, 2], 1), steps=120, epochs=2,
