@@ -581,6 +581,32 @@ def main():
                                      "frac": ach / (chip_peak * cus / 256.0) if cus else None, "cus": cus, "flop_per_row": flop_per_row,
                                      "note": "rows served per second x the model's flop per row, against the dense matrix-core peak of the CUs "
                                              "the evaluator side holds (%s storage)" % ("fp32" if mlp_dtype == "f32" else "bf16")}
+        # What the searcher SIMDs actually run into since round 4 (profiles/r0x_pool_pmc_sq.txt: a wave issues in 17 % of its cycles and
+        # waits for an ISSUE SLOT in another 21 %): instruction issue.  A SIMD takes its turn once every 4 cycles and issues at most one
+        # instruction of a class per turn, so a class of I wave-instructions per expansion bounds the chip at SIMDs x clock / (4 I).
+        # The counts are not measured by this process (SQ counters need rocprofv3): they are the committed profile of the same kernel
+        # and workload (profiles/issue.json, per call), divided by this run's expansions per call.
+        ipath = os.path.join(ROOT, "profiles", "issue.json")
+        if os.path.exists(ipath) and wl_name == "c21" and AGENTS_PER_GPU == 4096 and mlp_dtype == "f32" and form == "pool":
+            try:
+                ij = json.load(open(ipath))
+                per_exp = {k: v / max(1.0, exp_total / world / args.steps) for k, v in ij["wave_insts_per_call"].items()}
+                classes = {"valu": per_exp.get("valu", 0.0), "salu": per_exp.get("salu", 0.0), "lds": per_exp.get("lds", 0.0),
+                           "vmem": per_exp.get("vmem_rd", 0.0) + per_exp.get("vmem_wr", 0.0), "smem": per_exp.get("smem", 0.0)}
+                clock_ghz = (d["EVAL_LAYER_CLOCKS"] / (d["TICKS_TILE_KLOOP"] * 10.0)) if d.get("TICKS_TILE_KLOOP") else 2.4
+                simds = 256 * 4
+                worst = max(classes, key=lambda k: classes[k])
+                peak_issue = simds * clock_ghz * 1e9 / (4.0 * classes[worst]) if classes[worst] else None
+                out["roofline_issue"] = {"bound": "issue", "achieved": lat_rate, "peak": peak_issue, "unit": "expansions/s per GPU",
+                                         "frac": lat_rate / peak_issue if peak_issue else None, "binding_class": worst,
+                                         "wave_insts_per_expansion": {k: round(v, 1) for k, v in classes.items()},
+                                         "wave_insts_per_expansion_total": round(sum(classes.values()), 1),
+                                         "simds": simds, "clock_ghz": round(clock_ghz, 3), "cycles_per_issue_turn": 4,
+                                         "source": "profiles/issue.json (%s); clock: s_memtime over the evaluator's layers in this run" % ij["kernel"][:60],
+                                         "note": "peak = SIMDs x clock / (4 x the binding class's wave-instructions per expansion), all waves of the kernel counted "
+                                                 "(searchers, evaluators, polls); classes issue side by side from different waves, so the sum is not the bound"}
+            except Exception:
+                pass
         if mlp_dtype and form == "pool" and wl["kind"] != "dense" and d.get("EVAL_BATCHES", 0) > 0:
             # what actually bounds an in-kernel evaluator batch: the workgroup's weight stream from L2 -- every
             # batch pulls the whole model through one CU's vector-memory path -- against that path's 64 B per clock

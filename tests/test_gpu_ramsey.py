@@ -138,7 +138,7 @@ def test_ramsey_cascade_levels_wider_than_the_lds_frontier(az, orc, monkeypatch)
     go to the agent's slice of a device arena.  Here the LDS share is lowered to 64 entries (test hook), so that the levels of 100+
     ancestors this search reaches run through the arena: every tree and counter against the oracle."""
     monkeypatch.setenv("AZD_DEBUG_FRONTIER_LDS", "64")
-    n, sizes, B, seed, calls = 17, [4, 4], 48, 3, 800
+    n, sizes, B, seed, calls = 17, [4, 4], 96, 3, 800  # (the population of the test above: its widest level has 147 ancestors)
     tol = ([200, 200, 100, 100, 50, 50, 25, 25], 10)
     space = az.RamseySpaceNoEdgeRecolor(n, sizes)
     model = az.ActionModel(B, space.STATE_DIM, space.ACTION_DIM, hidden=(256, 256, 256), seed=seed)

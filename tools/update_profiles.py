@@ -8,7 +8,7 @@ import shutil
 import subprocess
 import sys
 
-R = sys.argv[1] if len(sys.argv) > 1 else "r04"
+R = sys.argv[1] if len(sys.argv) > 1 else "r05"
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 O = os.path.join(ROOT, "gpurun_out", "final_" + R)
 P = os.path.join(ROOT, "profiles")
@@ -150,6 +150,21 @@ for d_ in ("pmc_sq1", "pmc_sq2"):
 if sq:
     open(os.path.join(P, R + "_pool_pmc_sq.txt"), "w").write("# SQ counters of k_pool<3>, two rocprofv3 --pmc passes over bench.py --steps 800 --warmup 800 (tools/refresh_profiles.sh); tools/pmc_sq.py\n" + "".join(sq))
     print("".join(sq))
+# wave-instructions of k_pool per call, by class (the second SQ pass): what bench.py's roofline_issue block is computed from
+sq2 = newest("pmc_sq2/**/*counter_collection.csv")
+if sq2:
+    tot, disp = {}, set()
+    for r in csv.DictReader(open(sq2)):
+        if "k_pool" in r["Kernel_Name"]:
+            tot[r["Counter_Name"]] = tot.get(r["Counter_Name"], 0.0) + float(r["Counter_Value"])
+            disp.add(r["Dispatch_Id"])
+    calls = 800 * len(disp)
+    issue = {"kernel": "k_pool<3>, 4096 agents, fp32 3 x 256 (%s): rocprofv3 --pmc SQ_INSTS_* over bench.py --no-cpu-baseline --steps 800 --warmup 800, "
+                       "%d launches of 800 calls; ALL waves of the kernel (searchers, evaluators, waiting waves' polls)" % (R, len(disp)),
+             "calls": calls,
+             "wave_insts_per_call": {k.replace("SQ_INSTS_", "").lower(): v / calls for k, v in sorted(tot.items()) if k.startswith("SQ_INSTS_")}}
+    json.dump(issue, open(os.path.join(P, "issue.json"), "w"), indent=1)
+    print("k_pool wave-instructions per call:", {k: round(v) for k, v in issue["wave_insts_per_call"].items()})
 m = [x for x in open(os.path.join(O, "prof.log")).read().splitlines() if x.startswith('{"metric')] if os.path.exists(os.path.join(O, "prof.log")) else []
 if m:
     print("bench HIP-event avg in the profiled run:", json.loads(m[-1])["roofline"]["avg_launch_ms"])
