@@ -125,6 +125,8 @@ def lib():
     sig("azd_engine_argmin_data", C.c_int, vp, C.POINTER(Argmin))
     sig("azd_engine_agent_counters", C.c_int, vp, vp)
     sig("azd_engine_agent_counters_per_agent", C.c_int, vp)
+    sig("azd_engine_pool_agent_finish", C.c_int, vp, vp)
+    sig("azd_engine_pool_groups", C.c_int, vp, vp, vp, vp)
     sig("azd_engine_ramsey_argmin_data", C.c_int, vp, C.POINTER(RamseyArgmin))
     sig("azd_engine_ramsey_agent_counts", C.c_int, vp, C.c_int, vp, vp)
     sig("azd_ramsey_state_dim", C.c_int, C.c_int, C.c_int)

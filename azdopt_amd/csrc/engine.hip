@@ -144,6 +144,14 @@ struct azd_engine {
     bool counters_by_wave = false;       // a pool launch of the product build has run since the counters were cleared: the blocks of
                                          // azd_engine_agent_counters then hold what searcher WAVES counted, not what agents did
     uint32_t *d_resume = nullptr;        // [B] take-over of an aborted pool launch by k_async (StepLaunch::resume)
+    // evaluator groups of the pool step (PoolArgs::grp_*): device tables and per-slot exchange state, (re)built when the plan changes
+    int16_t *d_grp_tile = nullptr;
+    uint32_t *d_grp_lds = nullptr, *d_grp_desc = nullptr, *d_grp_cnt = nullptr, *d_grp_flag = nullptr;
+    size_t grp_flag_words = 0;
+    float *d_grp_x = nullptr;
+    size_t grp_x_floats = 0, grp_slots_alloc = 0;
+    std::vector<int16_t> grp_tile_host;  // what d_grp_tile holds (the plan is re-sent only when it changes)
+    std::vector<uint32_t> grp_lds_host;
     unsigned long long *d_log_key = nullptr;
     uint32_t *d_log_node = nullptr;
     int log_calls = 0;
@@ -185,6 +193,7 @@ struct azd_engine {
     size_t pool_slot_words = 0;
     int n_cus = 0;
     int pool_eval_wgs = 0, pool_search_wgs = 0; // of the last launch (diagnostics)
+    int pool_grp_g = 0, pool_grp_groups = 0, pool_grp_w = 0; // evaluator groups of the last pool launch (0: none)
     int pool_search_waves = 0;                  // searching waves of the last launch
     double pool_util_eval = 0, pool_util_search = 0; // busy share of the two sides in the last completed pool launch
     // Measured feedback on the split (the fitted constants give the first guess only).  Every pool launch reports how busy its two
@@ -905,6 +914,8 @@ int azd_engine_destroy(azd_engine *e) {
     if (e->h_win_log) (void)hipHostFree(e->h_win_log);
     if (e->h_win_flag) (void)hipHostFree(e->h_win_flag);
     if (e->d_pool) (void)hipFree(e->d_pool);
+    for (void *p : {(void *)e->d_grp_tile, (void *)e->d_grp_lds, (void *)e->d_grp_desc, (void *)e->d_grp_cnt, (void *)e->d_grp_x, (void *)e->d_grp_flag})
+        if (p) (void)hipFree(p);
     if (e->call_graph) (void)hipGraphExecDestroy(e->call_graph);
     for (int i = 0; i < azd_engine::MAX_SUBS; ++i) {
         if (e->sub_graph[i]) (void)hipGraphExecDestroy(e->sub_graph[i]);
@@ -993,6 +1004,80 @@ int azd_engine_roll_out_end(azd_engine *e, const float *h_theta, int *improved) 
     e->seen_improved = e->h_status->improved;
     return st;
 }
+// Evaluator groups (pool_step.inc: pool_eval_group): which member keeps which column tile of which layer in its LDS.
+// Greedy by size: the largest tiles first, each to the member that holds the fewest bytes so far and fewer than W tiles of that
+// layer.  The smallest group (a multiple of 8 workgroups) and the fewest waves per slot that fit the LDS are taken: a batch's
+// latency does not depend on g (a layer is one tile's MFMA chain per wave either way), the number of groups the CUs make does.
+struct GroupPlan {
+    int g = 0, W = 0;
+    size_t lds_bytes = 0;      // the fullest member's
+    uint32_t xstride = 0;      // floats per exchange buffer
+    std::vector<int16_t> tile; // [L][g][W]
+    std::vector<uint32_t> lds; // [L][g][W]
+};
+static bool plan_groups(const azd::FusedEval &fe, size_t lds_budget, int avail_wgs, int force_g, GroupPlan *out) {
+    const int L = fe.n_layers;
+    if (L < 1 || L > 7 || fe.bf16) return false;
+    std::vector<int> tiles(L), steps(L);
+    int max_tiles = 0;
+    uint32_t xs = 0;
+    for (int l = 0; l < L; ++l) {
+        steps[l] = (fe.dims[l] + 15) / 16;
+        tiles[l] = (fe.dims[l + 1] + 15) / 16;
+        max_tiles = std::max(max_tiles, tiles[l]);
+        if (l < L - 1) xs = std::max<uint32_t>(xs, (uint32_t)tiles[l] * 256u);
+        if (l < L - 1 && fe.dims[l + 1] % 16 != 0) return false; // a hidden layer's output is the next layer's whole k-steps
+    }
+    // the fewest waves per slot first (W = 1: sixteen batch slots per group), then the smallest group that fits the LDS and leaves
+    // room for two groups (config A: W = 1 needs g = 64 of the 192 CUs the searchers leave: 5.7 M expansions/s against 5.2 at g = 40, W = 2)
+    for (int W : {1, 2, 4})
+    for (int g = force_g > 0 ? force_g : 8; g <= avail_wgs && g <= 128; g += 8) {
+        {
+            if (force_g <= 0 && W < 4 && 2 * g > avail_wgs) break; // (a lone group only as the last resort)
+            if ((max_tiles + g - 1) / g > W) {
+                if (force_g > 0) break; // (a forced size is tried with every W, never enlarged)
+                continue;
+            }
+            struct Item { int l, t; size_t bytes; };
+            std::vector<Item> items;
+            for (int l = 0; l < L; ++l)
+                for (int t = 0; t < tiles[l]; ++t) items.push_back({l, t, (size_t)steps[l] * 1024});
+            std::stable_sort(items.begin(), items.end(), [](const Item &x, const Item &y) { return x.bytes > y.bytes; });
+            std::vector<size_t> load((size_t)g, 0);
+            std::vector<int> cnt((size_t)L * g, 0);
+            std::vector<int16_t> tile((size_t)L * g * W, (int16_t)-1);
+            std::vector<uint32_t> lds((size_t)L * g * W, 0u);
+            bool ok = true;
+            for (const Item &it : items) {
+                int best = -1;
+                for (int m = 0; m < g; ++m)
+                    if (cnt[(size_t)it.l * g + m] < W && (best < 0 || load[(size_t)m] < load[(size_t)best])) best = m;
+                if (best < 0 || load[(size_t)best] + it.bytes > lds_budget) {
+                    ok = false;
+                    break;
+                }
+                const int w = cnt[(size_t)it.l * g + best]++;
+                tile[((size_t)it.l * g + best) * W + w] = (int16_t)it.t;
+                lds[((size_t)it.l * g + best) * W + w] = (uint32_t)load[(size_t)best];
+                load[(size_t)best] += it.bytes;
+            }
+            if (!ok) {
+                if (force_g > 0) break;
+                continue;
+            }
+            out->g = g;
+            out->W = W;
+            out->lds_bytes = *std::max_element(load.begin(), load.end());
+            out->xstride = xs ? xs : 256u;
+            out->tile = tile;
+            out->lds = lds;
+            return true;
+        }
+        if (force_g > 0) break;
+    }
+    return false;
+}
+
 static int pool_clear(azd_engine *e, const azd::PoolArgs &pool) { // empty queues, nobody claimed, no call done
     AZD_HIP(hipMemsetAsync(pool.ctl, 0, sizeof(azd::PoolCtl), e->stream));
     AZD_HIP(hipMemsetAsync(pool.ready_slots, 0, e->pool_slot_words * sizeof(uint32_t), e->stream));
@@ -1483,7 +1568,78 @@ static int roll_out_impl(azd_engine *e, const azd::TolTable &t, int n_calls, int
         if (const char *env = getenv("AZD_POOL_EARLY_POST")) pool.early_post = atoi(env);
         pool.debug_abort_call = 0;
         if (const char *env = getenv("AZD_POOL_DEBUG_ABORT_CALL")) pool.debug_abort_call = (uint32_t)atoi(env);
+        // ---- evaluator groups (pool_eval_group): where a classic batch is long -- a model whose weights one CU streams in tens of
+        // microseconds -- and the population small enough that a few groups carry its rows.  AZD_POOL_EVAL_GROUP = 0: never;
+        // = g: groups of g workgroups whatever the model (tests, experiments).  f32 weight storage only.
+        pool.grp_g = pool.grp_w = pool.grp_groups = 0;
+        pool.grp_tile = nullptr;
+        pool.grp_lds = nullptr;
+        pool.grp_desc = pool.grp_cnt = nullptr;
+        pool.grp_x = nullptr;
+        pool.grp_flag = nullptr;
+        pool.grp_xstride = 0;
+        if (use_pool && fe.kind == 3 && !fe.bf16 && (size_t)B * (size_t)e->a.S * 4 < (1ull << 31)) {
+            double wbytes = 0;
+            for (int l = 0; l < fe.n_layers; ++l) wbytes += 4.0 * fe.dims[l] * fe.dims[l + 1];
+            int force_g = 0;
+            bool want = wbytes > 2.5e6 && B <= 1536; // (measured with config A's model: groups 5.7 / 9.8 / 11.0 M expansions/s at 512 / 1024 / 2048 agents, the classic form 3.5 / 6.8 / 13.2)
+            if (const char *env = getenv("AZD_POOL_EVAL_GROUP")) {
+                force_g = atoi(env);
+                want = force_g > 0;
+            }
+            GroupPlan gpl;
+            const int avail = capacity - n_search; // what the searchers leave (>= n_eval): idle CUs of a small population included
+            if (want && plan_groups(fe, (size_t)160 * 1024 - 2048, avail, force_g, &gpl)) {
+                const int n_groups = std::max(1, avail / gpl.g);
+                const int NS = 16 / gpl.W;
+                const size_t slots = (size_t)n_groups * NS;
+                if (!e->d_grp_tile) {
+                    AZD_HIP(hipMalloc(&e->d_grp_tile, (size_t)8 * 128 * 4 * sizeof(int16_t)));
+                    AZD_HIP(hipMalloc(&e->d_grp_lds, (size_t)8 * 128 * 4 * sizeof(uint32_t)));
+                }
+                if (slots > e->grp_slots_alloc || slots * 2 * gpl.xstride > e->grp_x_floats || slots * gpl.g * 16 > e->grp_flag_words) {
+                    AZD_HIP(hipStreamSynchronize(e->stream));
+                    (void)hipFree(e->d_grp_desc);
+                    (void)hipFree(e->d_grp_cnt);
+                    (void)hipFree(e->d_grp_x);
+                    (void)hipFree(e->d_grp_flag);
+                    e->d_grp_flag = nullptr;
+                    e->d_grp_desc = e->d_grp_cnt = nullptr;
+                    e->d_grp_x = nullptr;
+                    AZD_HIP(hipMalloc(&e->d_grp_desc, slots * 64 * 4));
+                    AZD_HIP(hipMalloc(&e->d_grp_cnt, slots * 8 * 32 * 4));
+                    AZD_HIP(hipMalloc(&e->d_grp_x, slots * 2 * gpl.xstride * 4));
+                    AZD_HIP(hipMalloc(&e->d_grp_flag, slots * gpl.g * 16 * 4));
+                    e->grp_flag_words = slots * gpl.g * 16;
+                    e->grp_slots_alloc = slots;
+                    e->grp_x_floats = slots * 2 * gpl.xstride;
+                }
+                if (gpl.tile != e->grp_tile_host || gpl.lds != e->grp_lds_host) {
+                    AZD_HIP(hipStreamSynchronize(e->stream));
+                    AZD_HIP(hipMemcpy(e->d_grp_tile, gpl.tile.data(), gpl.tile.size() * sizeof(int16_t), hipMemcpyHostToDevice));
+                    AZD_HIP(hipMemcpy(e->d_grp_lds, gpl.lds.data(), gpl.lds.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+                    e->grp_tile_host = gpl.tile;
+                    e->grp_lds_host = gpl.lds;
+                }
+                pool.grp_g = gpl.g;
+                pool.grp_w = gpl.W;
+                pool.grp_groups = n_groups;
+                pool.grp_tile = e->d_grp_tile;
+                pool.grp_lds = e->d_grp_lds;
+                pool.grp_desc = e->d_grp_desc;
+                pool.grp_cnt = e->d_grp_cnt;
+                pool.grp_x = e->d_grp_x;
+                pool.grp_flag = e->d_grp_flag;
+                pool.grp_xstride = gpl.xstride;
+                n_eval = n_groups * gpl.g; // every evaluator workgroup is a group member
+                pool.n_eval = n_eval;
+                if (gpl.lds_bytes > dyn_bytes) dyn_bytes = gpl.lds_bytes;
+            }
+        }
         pool_blocks = n_eval + n_search;
+        e->pool_grp_g = pool.grp_g;
+        e->pool_grp_groups = pool.grp_groups;
+        e->pool_grp_w = pool.grp_w;
         e->pool_eval_wgs = n_eval;
         e->pool_search_wgs = n_search;
         e->pool_search_waves = (n_search - pool.n_express) * 16 + pool.n_express * (int)pool.express_waves;
@@ -1533,6 +1689,12 @@ static int roll_out_impl(azd_engine *e, const azd::TolTable &t, int n_calls, int
             if (use_pool && !e->pool_clean) {
                 st = pool_clear(e, pool);
                 if (st) return st;
+            }
+            if (use_pool && pool.grp_g > 0) { // batch numbers and arrival counts of the groups' slots start from zero in every launch
+                const size_t slots = (size_t)pool.grp_groups * (16 / pool.grp_w);
+                AZD_HIP(hipMemsetAsync(pool.grp_desc, 0, slots * 64 * 4, e->stream));
+                AZD_HIP(hipMemsetAsync(pool.grp_cnt, 0, slots * 8 * 32 * 4, e->stream));
+                AZD_HIP(hipMemsetAsync(pool.grp_flag, 0, slots * pool.grp_g * 16 * 4, e->stream));
             }
             if (!use_barrier && !e->log_clean) {
                 AZD_HIP(hipMemsetAsync(e->d_log_key, 0xFF, (size_t)e->log_calls * sizeof(unsigned long long), e->stream));
@@ -2394,6 +2556,24 @@ int azd_engine_pool_utilisation(azd_engine *e, double *eval_busy, double *search
     if (!e) return AZD_ERR_INVALID_ARGUMENT;
     if (eval_busy) *eval_busy = e->pool_util_eval;
     if (search_busy) *search_busy = e->pool_util_search;
+    return AZD_OK;
+}
+int azd_engine_pool_groups(azd_engine *e, int *members, int *groups, int *waves_per_slot) {
+    if (!e) return AZD_ERR_INVALID_ARGUMENT;
+    if (members) *members = e->pool_grp_g;
+    if (groups) *groups = e->pool_grp_groups;
+    if (waves_per_slot) *waves_per_slot = e->pool_grp_w;
+    return AZD_OK;
+}
+int azd_engine_pool_agent_finish(azd_engine *e, uint64_t *ticks_out) {
+    if (!e || !ticks_out) return AZD_ERR_INVALID_ARGUMENT;
+    AZD_ENTER(e);
+    if (!e->pool.stamp) {
+        azd::g_last_error = "pool_agent_finish: this engine has run no pool step";
+        return AZD_ERR_INVALID_ARGUMENT;
+    }
+    AZD_HIP(hipStreamSynchronize(e->stream));
+    AZD_HIP(hipMemcpy(ticks_out, e->pool.stamp, (size_t)e->a.B * 8, hipMemcpyDeviceToHost));
     return AZD_OK;
 }
 int azd_engine_pool_split(azd_engine *e, int *eval_wgs, int *search_wgs) {

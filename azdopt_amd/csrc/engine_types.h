@@ -298,6 +298,18 @@ struct PoolArgs {
     uint32_t eval_out_off; // offset (floats) of the head's output inside a row
     uint32_t eval_rows;    // rows an evaluator batch may hold: 16, or 32 (two MFMA row tiles per weight fragment)
     uint32_t *post_call;   // [B] FusedEval::kind 4 only: the call whose row the agent has posted (the evaluator hashes it)
+    // Evaluator GROUPS (round 5; pool_step.inc: pool_eval_group): blocks [0, grp_groups * grp_g) serve batches g workgroups at a time,
+    // member j keeping the weight fragments of its column tiles of every layer in LDS for the whole launch; the other evaluator
+    // blocks [grp_groups * grp_g, n_eval) are workgroups of the classic form.  grp_g = 0: no groups.
+    int grp_g, grp_w, grp_groups;    // members per group; waves per member and batch slot (= column tiles per member and layer, at most); groups
+    const int16_t *grp_tile;         // [layer][member][w]: the column tile, -1 none
+    const uint32_t *grp_lds;         // [layer][member][w]: byte offset of the tile's fragments in the member's LDS
+    uint32_t *grp_desc;              // [group][slot][64]: word 0 batch number (0xFFFFFFFF: leave), 1 rows, 16.. agents, 32.. request bytes
+    uint32_t *grp_cnt;               // [group][slot][8][32]: column tiles of layer l done, over all batches of the slot (a line each)
+    uint32_t *grp_flag;              // [group][slot][member][16]: word l = the last batch whose layer l is complete, word 7 = the last batch published
+                                     // (0xFFFFFFFF: leave); written by ONE wave (the layer's last arriver / the slot's leader), polled by that member only
+    float *grp_x;                    // [group][slot][2][grp_xstride]: a batch's activations between the layers, fragment-major
+    uint32_t grp_xstride;            // floats: 256 x the widest hidden layer's column tiles
     uint32_t debug_abort_call; // test hook (AZD_POOL_DEBUG_ABORT_CALL = k): evaluator workgroup 0 raises PoolCtl::abort after its k-th batch; 0: off
     // Run-ahead window (azd_engine_run_ahead; the kernel's window instantiation only): the wave that completes a call for the
     // LAST agent hands the call's argmin candidate to the host while the launch goes on

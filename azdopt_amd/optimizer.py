@@ -323,6 +323,18 @@ class NablaOptimizer:
         _lib.check(self._L.azd_engine_agent_counters(self._h, _lib.ptr(out)), "agent_counters")
         return {k: out[:, v].copy() for k, v in _lib.CTR.items()}
 
+    def pool_groups(self):
+        """evaluator groups of the last pool launch: (members per group, groups, waves per slot); (0, 0, 0) = the classic form"""
+        g, n, w = C.c_int(), C.c_int(), C.c_int()
+        _lib.check(self._L.azd_engine_pool_groups(self._h, C.byref(g), C.byref(n), C.byref(w)), "pool_groups")
+        return g.value, n.value, w.value
+
+    def pool_agent_finish_ms(self):
+        """pool step: when each agent was through with the last launch's calls, ms from the launch's start (numpy [batch])"""
+        out = np.zeros(self.batch, np.uint64)
+        _lib.check(self._L.azd_engine_pool_agent_finish(self._h, _lib.ptr(out)), "pool_agent_finish")
+        return out.astype(np.float64) * 1e-5
+
     def set_timing(self, enabled=True):
         _lib.check(self._L.azd_engine_set_timing(self._h, int(enabled)), "set_timing")
 

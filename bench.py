@@ -581,6 +581,19 @@ def main():
                                      "frac": ach / (chip_peak * cus / 256.0) if cus else None, "cus": cus, "flop_per_row": flop_per_row,
                                      "note": "rows served per second x the model's flop per row, against the dense matrix-core peak of the CUs "
                                              "the evaluator side holds (%s storage)" % ("fp32" if mlp_dtype == "f32" else "bf16")}
+        # The epoch's tail (round-4 verdict, item 5): a launch lasts as long as its slowest agent's chain of calls; how far the
+        # population's median is from that is what the barrier at the end of a launch costs.  Of the LAST launch of the timed region.
+        if form == "pool" and wl["kind"] != "dense":
+            try:
+                fin = opt.pool_agent_finish_ms()
+                fin = fin[fin > 0]
+                if fin.size:
+                    p50, p90, p99, mx = (float(np.percentile(fin, q)) for q in (50, 90, 99, 100))
+                    out["epoch_tail"] = {"calls_in_launch": int(min(args.steps, args.chunk, EPOCH_CALLS)), "agent_finish_ms": {"p50": p50, "p90": p90, "p99": p99, "max": mx},
+                                         "launch_over_median": mx / p50 if p50 else None,
+                                         "note": "when each agent was through with the last launch's calls (azd_engine_pool_agent_finish); max = the launch"}
+            except Exception:
+                pass
         # What the searcher SIMDs actually run into since round 4 (profiles/r0x_pool_pmc_sq.txt: a wave issues in 17 % of its cycles and
         # waits for an ISSUE SLOT in another 21 %): instruction issue.  A SIMD takes its turn once every 4 cycles and issues at most one
         # instruction of a class per turn, so a class of I wave-instructions per expansion bounds the chip at SIMDs x clock / (4 I).

@@ -451,6 +451,18 @@ void *azd_engine_stream(azd_engine *e); /* hipStream_t the engine launches on */
 #define AZD_STEP_PER_CALL_GRAPH 5 /* AZD_STEP_PER_CALL with the launches of a call captured in a hipGraph and replayed */
 int azd_engine_step_form(azd_engine *e, int *form, const char **reason);
 /* how the last pool-step launch split the CUs: evaluator / searcher workgroups */
+/* Evaluator groups of the last pool launch: `members` workgroups serve a batch together, each keeping the weight fragments of its
+ * column tiles of every layer in LDS for the whole launch (no weight stream per batch; the batch's activations travel between the
+ * layers through device memory), `groups` of them, a workgroup's waves in slots of `waves_per_slot`.  0 members: the classic form
+ * (one workgroup per batch, weights streamed from L2).  The engine forms groups where a classic batch is long (fp32 weights beyond
+ * 2.5 MB, at most 2048 agents: BASELINE configs[0], the reference's 304-512-1024-512-152); AZD_POOL_EVAL_GROUP = 0 / g overrides.
+ * Same rows to the bit either way. */
+int azd_engine_pool_groups(azd_engine *e, int *members, int *groups, int *waves_per_slot);
+/* Pool step (product build): for every agent, when it was through with the calls of the LAST pool launch, in 100 MHz ticks from the
+ * launch's first workgroup -- the launch lasts as long as its slowest agent's chain of calls (tree/mod.rs:113-232 is serial per
+ * tree), so max over agents = the launch, and the distance of the median from it is what the epoch's barrier costs.
+ * out[batch].  The diagnostic build (make PROFILE=1) uses the array for its own stamps: values are not finish times there. */
+int azd_engine_pool_agent_finish(azd_engine *e, uint64_t *ticks_out);
 int azd_engine_pool_split(azd_engine *e, int *eval_wgs, int *search_wgs);
 /* ... and how busy its two sides were: the share of the launch an evaluator workgroup spent on batches, and the share a
  * searcher wave spent with an agent in hand (the engine moves the split towards equal shares from launch to launch) */

@@ -418,7 +418,7 @@ def test_asynchronous_step_with_the_real_model_in_one_launch_against_the_oracle(
         assert_tree_equal(opt.get_tree(i), oe.export_tree(i), f"agent {i}")
 
 
-@pytest.mark.parametrize("model_kind", ["hash", "mlp"])
+@pytest.mark.parametrize("model_kind", ["hash", "mlp", "mlp_groups"])
 def test_pool_abort_is_taken_over_by_the_async_step(az, orc, model_kind, monkeypatch):
     """PoolCtl::abort (a wait ran into its bound) no longer fails the call: the asynchronous step takes the launch over
     where every agent stands -- some through all calls, some waiting for a row that no evaluator will serve, some never
@@ -434,6 +434,8 @@ def test_pool_abort_is_taken_over_by_the_async_step(az, orc, model_kind, monkeyp
 
     ref = az.NablaOptimizer.par_new(space, roots, make_model(), B, pool_step=False)
     imp_ref = ref.par_roll_out_episodes(TOL_REF, n_calls=calls)
+    if model_kind == "mlp_groups":  # the evaluator groups' waits leave on the flag too (the hook sits in the first slot's leader there)
+        monkeypatch.setenv("AZD_POOL_EVAL_GROUP", "8")
     monkeypatch.setenv("AZD_POOL_DEBUG_ABORT_CALL", "7")
     opt = az.NablaOptimizer.par_new(space, roots, make_model(), B, pool_step=True)
     imp = opt.par_roll_out_episodes(TOL_REF, n_calls=calls)
@@ -632,3 +634,54 @@ def test_agent_counters_say_when_they_are_not_per_agent(az):
     parents, permitted = pool._roots(*roots)
     _lib.check(pool._L.azd_engine_par_new(pool._h, _lib.ptr(parents), _lib.ptr(permitted)), "par_new")
     assert pool._L.azd_engine_agent_counters_per_agent(pool._h) == 1
+
+
+@pytest.mark.parametrize("g", [8, 16])
+def test_evaluator_groups_equal_the_classic_form_and_the_async_step(az, monkeypatch, g):
+    """Evaluator groups (pool_eval_group: g workgroups per batch, weight slices resident in LDS, activations exchanged through device
+    memory) compute every prediction row with mlp_tile_task's MFMA sequence: identical rows, hence identical trees, counters and
+    argmin as the classic evaluator workgroups and as the asynchronous step -- forced here on the 3 x 256 model (AZD_POOL_EVAL_GROUP)."""
+    n, B, seed, calls = 19, 320, 12, 150
+    space = az.ROTModifyParentsOnce(n)
+    roots = space.generate_roots(seed, B)
+    runs = []
+    for form in ("group", "classic", "async"):
+        if form == "group":
+            monkeypatch.setenv("AZD_POOL_EVAL_GROUP", str(g))
+        else:
+            monkeypatch.setenv("AZD_POOL_EVAL_GROUP", "0")
+        model = az.ActionModel(B, space.STATE_DIM, space.ACTION_DIM, hidden=(256, 256, 256), seed=seed)
+        o = az.NablaOptimizer.par_new(space, roots, model, B, pool_step=form != "async")
+        imp = o.par_roll_out_episodes(TOL_REF, n_calls=calls)
+        runs.append((o, imp))
+    assert runs[0][0].step_form() == ("pool", "") and runs[0][0].pool_groups()[0] == g and runs[0][0].pool_groups()[1] >= 1
+    assert runs[1][0].step_form() == ("pool", "") and runs[1][0].pool_groups() == (0, 0, 0)
+    c = runs[0][0].counters()
+    assert c["EVAL_ROWS"] == c["EXPANSIONS"] > 50 * B and c["FAILED"] == 0
+    for o, imp in runs[1:]:
+        same_engines(runs[0][0], runs[0][1], o, imp, range(0, B, 3))
+        assert np.array_equal(runs[0][0].predictions().view(np.uint32), o.predictions().view(np.uint32))
+
+
+def test_evaluator_groups_at_the_reference_shape_against_the_oracle(az, orc):
+    """BASELINE configs[0] (the reference's own run: 512 agents, 304-512-1024-512-152 fp32, 04-c21-tree.rs:46-54): the engine forms
+    evaluator groups by itself there (5.1 MB of weights per classic batch).  One launch of 300 calls of the product kernel against
+    the oracle fed with the classic tile task's rows of its own states (debug_tile_forward), then an optimiser step and 100 more."""
+    n, B, seed, calls = 19, 512, 9, 300
+    space = az.ROTModifyParentsOnce(n)
+    roots = space.generate_roots(seed, B)
+    model = az.ActionModel(B, space.STATE_DIM, space.ACTION_DIM, hidden=(512, 1024, 512), seed=seed)
+    opt = az.NablaOptimizer.par_new(space, roots, model, B, pool_step=True)
+    oe = orc.Engine(n, B, threads=8)
+    oe.new_begin(*roots)
+    oe.new_end(opt.predictions())
+    _follow_with_the_oracle(opt, oe, TOL_REF, calls)
+    members, groups, waves = opt.pool_groups()
+    assert opt.step_form() == ("pool", "") and members >= 8 and groups >= 1 and waves in (1, 2, 4), (members, groups, waves)
+    for i in range(0, B, 7):
+        assert_tree_equal(opt.get_tree(i), oe.export_tree(i), f"agent {i}")
+    oe.observe(200)  # (optimizer/mod.rs:262-267: the training step leaves the ROOTS' vectors in state_vecs, on both sides)
+    assert np.isfinite(opt.par_update_model(200))  # new weights: the next launch loads its LDS slices afresh
+    _follow_with_the_oracle(opt, oe, TOL_REF, 100)
+    for i in range(0, B, 7):
+        assert_tree_equal(opt.get_tree(i), oe.export_tree(i), f"agent {i} after the optimiser step")

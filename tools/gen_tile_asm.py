@@ -164,6 +164,72 @@ __device__ __forceinline__ void %s(azd_tile_acc &acc, %s &ring, int &state, cons
 ''' % (name, rt, 2048 if bf16 else 4096, 2048 if bf16 else 4096, text, ring_ops, ", ".join(clob)))
 
 
+def body_ga(stride):
+    """The group evaluator's k loop (pool_step.inc: pool_eval_group): the ROWS' quads come from device memory -- the agents' state
+    vectors (64 B per k-step and row) or the exchange buffer of the layer before (fragment-major: 1 KB per k-step) -- by sc1
+    buffer loads, two rings of 8 k-steps as above; the WEIGHT quads come from the member's LDS (1 KB per k-step), one step ahead."""
+    RB = RA + 32
+    lines = []
+
+    def loads(ring):
+        out = []
+        for j in range(8):
+            if stride == 64:
+                out.append("buffer_load_dwordx4 %s, %%[vo], %%[rs], 0 offen offset:%d sc1" % (v(ring + 4 * j, 4), 64 * j))
+            else:
+                out.append("buffer_load_dwordx4 %s, %%[vo], %%[rs], %s offen offset:%d sc1" % (v(ring + 4 * j, 4), "0" if j < 4 else "%[k4]", 1024 * (j & 3)))
+        return out
+
+    def consume(ring):
+        out = ["ds_read_b128 %s, %%[bp]" % v(A0, 4), "ds_read_b128 %s, %%[bp] offset:1024" % v(A0 + 4, 4)]
+        for j in range(8):
+            b = A0 if (j & 1) == 0 else A0 + 4
+            if j:
+                out += ["s_add_i32 %[t0], %[done], " + str(j), "s_cmp_ge_i32 %[t0], %[steps]", "s_cbranch_scc1 9f"]
+            out.append("s_waitcnt lgkmcnt(1)" if j < 7 else "s_waitcnt lgkmcnt(0)")
+            for i in range(4):
+                out.append("v_mfma_f32_16x16x4_f32 %%[acc], %s, %s, %%[acc]" % (v(ring + 4 * j + i), v(b + i)))
+            if j + 2 < 8:
+                out.append("ds_read_b128 %s, %%[bp] offset:%d" % (v(b, 4), 1024 * (j + 2)))
+        return out
+
+    lines += loads(RA)
+    lines += ["s_mov_b32 %[done], 0", "1:"]
+    for ring, other in ((RA, RB), (RB, RA)):
+        lines += ["s_add_i32 %[t0], %[done], 8", "s_cmp_lt_i32 %[t0], %[steps]", "s_cbranch_scc0 2f"]
+        lines += ["v_add_u32 %%[vo], 0x%x, %%[vo]" % (8 * stride)]
+        lines += loads(other)
+        lines += ["s_waitcnt vmcnt(8)", "s_branch 3f", "2:", "s_waitcnt vmcnt(0)", "3:"]
+        lines += consume(ring)
+        lines += ["s_add_i32 %[done], %[done], 8", "v_add_u32 %[bp], 0x2000, %[bp]", "s_cmp_ge_i32 %[done], %[steps]", "s_cbranch_scc1 9f"]
+    lines += ["s_branch 1b", "9:", "s_waitcnt vmcnt(0) lgkmcnt(0)"]
+    return lines
+
+
+def emit_ga(name, stride):
+    text = "\\n\\t\"\n        \"".join(body_ga(stride))
+    clob = ['"memory"', '"scc"'] + ['"v%d"' % r for r in list(range(A0, A0 + 8)) + list(range(RA, RA + 64))]
+    return ('''// ---- generated by tools/gen_tile_asm.py: do not edit
+// The group evaluator's k loop: rows' quads from device memory (buffer resource `rs`, this lane's byte offset of k-step 0 in `vo`,
+// %d B per k-step; sc1: L1 bypassed), weight quads from LDS (`bp`: this lane's quad of k-step 0, 1 KB per k-step).  A ragged last
+// group still issues 8 requests: they stay inside the buffer resource or are dropped by its range check.
+__device__ __forceinline__ void %s(azd_tile_acc &acc, const azd_tile_u4 rs_in, uint32_t vo, uint32_t bp, const int steps) {
+    azd_tile_u4 rs; // (made uniform for the compiler's eyes: an "s" operand)
+    rs[0] = (uint32_t)__builtin_amdgcn_readfirstlane((int)rs_in[0]);
+    rs[1] = (uint32_t)__builtin_amdgcn_readfirstlane((int)rs_in[1]);
+    rs[2] = (uint32_t)__builtin_amdgcn_readfirstlane((int)rs_in[2]);
+    rs[3] = (uint32_t)__builtin_amdgcn_readfirstlane((int)rs_in[3]);
+    int done, t0;
+    const int k4 = __builtin_amdgcn_readfirstlane(4096);
+    asm volatile(
+        "%s\\n\\t"
+        : [acc] "+v"(acc), [vo] "+v"(vo), [bp] "+v"(bp), [done] "=&s"(done), [t0] "=&s"(t0)
+        : [rs] "s"(rs), [k4] "s"(k4), [steps] "s"(__builtin_amdgcn_readfirstlane(steps))
+        : %s);
+}
+''' % (stride, name, text, ", ".join(clob)))
+
+
 def main():
     with open(OUT, "w") as f:
         f.write("// tile_task_asm.inc -- the software-pipelined k loop of an evaluator tile task (see tools/gen_tile_asm.py for the why and the\n"
@@ -177,6 +243,9 @@ def main():
                 "           ((unsigned long long)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(x >> 32)) << 32);\n}\n")
         f.write(emit("tile_k_loop_f32", False))
         f.write(emit("tile_k_loop_bf16", True))
+        f.write("typedef unsigned int azd_tile_u4 __attribute__((ext_vector_type(4)));\n")
+        f.write(emit_ga("tile_k_loop_f32_ga64", 64))
+        f.write(emit_ga("tile_k_loop_f32_ga1024", 1024))
         f.write(emit_chained("tile_k_chain_f32", False))
         f.write(emit_chained("tile_k_chain_bf16", True))
     print("wrote", os.path.normpath(OUT))
