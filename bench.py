@@ -548,7 +548,10 @@ def main():
             "step_form": form, "step_form_reason": form_why, "pool_split": list(opt.pool_split()) if form == "pool" else None,
             "evaluator_form": ("outside the kernel: batched bf16 GEMM launches over the rows the searchers have posted, replayed from a hipGraph "
                                "on a second stream while the searchers run") if (form == "pool" and wl["kind"] == "dense") else
-                              ("evaluator workgroups inside the kernel" if form == "pool" else None),
+                              (("evaluator GROUPS inside the kernel: %d workgroups serve a batch together, their column tiles' weights resident in LDS "
+                                "for the whole launch, the batch's activations exchanged through device memory (%d groups, %d-wave slots)" % opt.pool_groups())
+                               if (form == "pool" and opt.pool_groups()[0] > 0) else
+                               ("evaluator workgroups inside the kernel" if form == "pool" else None)),
             "epoch_boundary_in_timed_region": n_bound > 0, "epoch_boundaries_in_timed_region": n_bound,
             "best_cost_found": best_cost, "best_eval": best_eval,
             "expansions": exp_total, "terminals": d["TERMINALS"], "transpositions": d["TRANSPOSITIONS"],
@@ -620,7 +623,19 @@ def main():
                                                  "(searchers, evaluators, polls); classes issue side by side from different waves, so the sum is not the bound"}
             except Exception:
                 pass
-        if mlp_dtype and form == "pool" and wl["kind"] != "dense" and d.get("EVAL_BATCHES", 0) > 0:
+        if mlp_dtype and form == "pool" and wl["kind"] != "dense" and d.get("EVAL_BATCHES", 0) > 0 and opt.pool_groups()[0] > 0:
+            # evaluator groups: no weight stream -- a batch's time is its layer edges (slice out, arrival count, flags, rows' quads in) plus one
+            # tile's MFMA chain per layer; what it would be as ONE workgroup's stream is beside it (profiles/r05_bench_lines.txt: AZD_POOL_EVAL_GROUP=0)
+            g_, ng_, w_ = opt.pool_groups()
+            wbytes = sum(a * b for a, b in zip((space.STATE_DIM,) + HIDDEN, HIDDEN + (space.ACTION_DIM,))) * 4
+            chain = sum(((a + 15) // 16) * 4 * 40 for a in (space.STATE_DIM,) + HIDDEN)  # dependent v_mfma_f32_16x16x4_f32 of one tile per layer, 40 clocks each
+            us_per_batch = d["TICKS_BATCH"] / 100.0 / d["EVAL_BATCHES"]
+            out["evaluator_groups"] = {"members": g_, "groups": ng_, "waves_per_slot": w_, "slots": ng_ * (16 // w_), "us_per_batch": us_per_batch,
+                                       "rows_per_batch": d["EVAL_ROWS"] / d["EVAL_BATCHES"], "layer_edges": len(HIDDEN) + 1,
+                                       "mfma_chain_us_at_2p4ghz": chain / 2400.0, "weight_bytes_resident": wbytes,
+                                       "note": "us_per_batch = batch taken -> rows released, by the slot's leader; the classic form streams the "
+                                               "weight_bytes through one CU per batch instead (config A: 86 us per batch)"}
+        elif mlp_dtype and form == "pool" and wl["kind"] != "dense" and d.get("EVAL_BATCHES", 0) > 0:
             # what actually bounds an in-kernel evaluator batch: the workgroup's weight stream from L2 -- every
             # batch pulls the whole model through one CU's vector-memory path -- against that path's 64 B per clock
             wbytes = sum(a * b for a, b in zip((space.STATE_DIM,) + HIDDEN, HIDDEN + (space.ACTION_DIM,))) * (4 if mlp_dtype == "f32" else 2)

@@ -2,8 +2,8 @@
 # Profile refresh of a round (run on the GPU box through gpurun; tools/update_profiles.py copies the summaries to profiles/):
 #   tools/refresh_profiles.sh r04 [part ...]     parts: bench stats tcc tcc20 l2 sq gemm split curve examples  (default: all)
 export TMPDIR=/tmp
-R=${1:-r03}; shift
-PARTS=${*:-bench stats tcc tcc20 l2 sq gemm split curve examples}
+R=${1:-r05}; shift
+PARTS=${*:-bench stats tcc tcc20 l2 sq insts gemm split curve examples}
 O=gpurun_out/final_$R
 mkdir -p $O
 has() { [[ " $PARTS " == *" $1 "* ]]; }
@@ -12,6 +12,7 @@ if has bench; then
   timeout -k 10 200 python bench.py --steps 20 --warmup 5 --no-cpu-baseline > $O/bench_driver20.log 2>&1
   timeout -k 10 200 python bench.py --no-cpu-baseline --step async > $O/bench_B_async.log 2>&1
   for cfg in A C D; do timeout -k 10 300 python bench.py --no-cpu-baseline --config $cfg > $O/bench_$cfg.log 2>&1; done
+  AZD_POOL_EVAL_GROUP=0 timeout -k 10 300 python bench.py --no-cpu-baseline --config A > $O/bench_A_classic.log 2>&1
   timeout -k 10 300 python bench.py --no-cpu-baseline --agents 8192 > $O/bench_B8192.log 2>&1
   timeout -k 10 400 python bench.py --config E --steps 400 --warmup 50 > $O/bench_E.log 2>&1
   AZD_DENSE_NO_POOL=1 timeout -k 10 400 python bench.py --config E --steps 400 --warmup 50 --no-cpu-baseline > $O/bench_E_per_call.log 2>&1
@@ -44,6 +45,14 @@ if has sq; then
   timeout -k 10 300 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_SCA --kernel-trace --output-format csv -d $O/pmc_sq1 -- python3 bench.py --no-cpu-baseline --steps 800 --warmup 800 > $O/pmc_sq1.log 2>&1
   timeout -k 10 300 rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_SMEM SQ_WAVES SQ_INSTS_VALU_MFMA_MOPS_F32 --kernel-trace --output-format csv -d $O/pmc_sq2 -- python3 bench.py --no-cpu-baseline --steps 800 --warmup 800 > $O/pmc_sq2.log 2>&1
   echo sq done
+fi
+if has insts; then  # the instruction table (profiles/<round>_pool_insts.txt): phase stamps of the diagnostic build + SQ_INSTS_* per kernel of the pool step and of the launch-per-phase form
+  { echo "## phase stamps, diagnostic build (tools/pool_cycle.py; make PROFILE=1)"; AZD_LIB=azdopt_amd/libazdopt_amd_prof.so timeout -k 10 200 python tools/pool_cycle.py 4096 800
+    for form in pool per_call; do n=400; [ $form = per_call ] && n=100
+      echo "## rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_SMEM SQ_WAVES SQ_INSTS_VALU_MFMA_MOPS_F32 -- python3 tools/inst_run.py $form 4096 $n"
+      timeout -k 10 200 rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_SMEM SQ_WAVES SQ_INSTS_VALU_MFMA_MOPS_F32 --kernel-trace --output-format csv -d $O/pmc_i_$form -- python3 tools/inst_run.py $form 4096 $n 2>/dev/null | grep -E "^form|^EXPANSIONS"
+      python tools/pmc_kernels.py $O/pmc_i_$form | grep -E "k_pool|k_rollout|k_add_actions|k_gemm|k_argmin" ; rm -rf $O/pmc_i_$form; done; } > $O/insts.txt 2>&1
+  echo insts done
 fi
 if has gemm; then
   { timeout -k 10 200 python tools/time_gemm16.py; echo "# zero-filled operands (they read higher; for comparison with figures quoted that way):"; AZD_GEMM_ZEROS=1 timeout -k 10 200 python tools/time_gemm16.py 8192 4096 4096; for dt in bf16 f32; do timeout -k 10 100 python tools/time_gemm.py $dt 8192; timeout -k 10 100 python tools/time_gemm.py $dt 65536 304,256,256,256,152; timeout -k 10 100 python tools/time_gemm.py $dt 8192 4096,4096,4096; done; AZD_GEMM_OLD=1 timeout -k 10 100 python tools/time_gemm.py bf16 8192;

@@ -125,7 +125,7 @@ for src, dst in (("prof/**/*kernel_stats.csv", "_pool_kernel_stats.csv"), ("prof
         for row in csv.DictReader(open(f)):
             if any(k in row["Name"] for k in ("k_pool", "k_gemm16", "k_rollout", "k_gemm_bf16", "k_ext_")):
                 print("rocprofv3 %-28s %-60s launches %5s avg ms %.4f" % (dst, row["Name"][:60], row["Calls"], float(row["AverageNs"]) / 1e6))
-names = ("default", "driver20", "B_async", "A", "C", "D", "B8192", "E", "E_epochs", "E_per_call", "E612", "E612_epochs")
+names = ("default", "driver20", "B_async", "A", "A_classic", "C", "D", "B8192", "E", "E_epochs", "E_per_call", "E612", "E612_epochs")
 with open(os.path.join(P, R + "_bench_lines.txt"), "w") as f:
     for name in names:
         line = bench_line(name)
@@ -143,6 +143,15 @@ for src, dst, head in (("gemm.txt", "_gemm.txt", "# tools/time_gemm16.py (the LD
                        ("pool_split.txt", "_pool_split.txt", "# tools/split_util.py (busy shares of the two sides across fixed splits) and tools/split_feedback.py (the engine's feedback)\n")):
     if os.path.exists(os.path.join(O, src)):
         open(os.path.join(P, R + dst), "w").write(head + txt(src))
+if os.path.exists(os.path.join(O, "insts.txt")):
+    head = ("# %s_pool_insts.txt -- where the searcher's instructions go (round-4 verdict, item 2).  tools/refresh_profiles.sh insts:\n"
+            "#  * phase stamps of the diagnostic build (100 MHz wall clock around each phase of rollout_agent, per agent and call with a new node);\n"
+            "#  * wave-instructions by class, per kernel, of the pool step (one launch of 400 calls) and of the launch-per-phase form (100 calls:\n"
+            "#    k_rollout = the search proper -- selection levels, table probes, new nodes with lambda_1 / matching / row, cascades --, k_add_actions,\n"
+            "#    k_gemm = the evaluator as batched launches), with the expansions and events of the counted launches.\n"
+            "# Per expansion (divide by EXPANSIONS): see DESIGN.md section 5 / 6a.  PC sampling is not available on this pool (refused), so the split of\n"
+            "# k_rollout's instructions by phase is by the stamps' time shares, not by counting.\n" % R)
+    open(os.path.join(P, R + "_pool_insts.txt"), "w").write(head + txt("insts.txt"))
 sq = []
 for d_ in ("pmc_sq1", "pmc_sq2"):
     if os.path.isdir(os.path.join(O, d_)):
