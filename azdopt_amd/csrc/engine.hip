@@ -777,7 +777,7 @@ int azd_engine_create(azd_engine **out, const azd_engine_config *cfg, azd_evalua
         const int k = atoi(v);
         if (k >= 64 && k <= azd::FRONTIER_CAP && k % 64 == 0) a.fr_lds = (uint32_t)k;
     }
-    TRY(e->alloc(&a.fr_spill, B * 4 * a.node_cap)); // cascade frontier levels beyond the LDS's FRONTIER_CAP entries: (node, x) x node_cap x 2 levels
+    if (ramsey) TRY(e->alloc(&a.fr_spill, B * 4 * a.node_cap)); // cascade frontier levels beyond the LDS's FRONTIER_CAP entries: (node, x) x node_cap x 2 levels (RamseySpace::FRONTIER_SPILL)
     TRY(e->alloc(&a.cand_c, B));
     TRY(e->alloc(&a.cand_node, B));
     TRY(e->alloc(&a.counters, B * azd::NUM_COUNTERS));
@@ -1581,7 +1581,7 @@ static int roll_out_impl(azd_engine *e, const azd::TolTable &t, int n_calls, int
         pool.grp_x = nullptr;
         pool.grp_flag = nullptr;
         pool.grp_xstride = 0;
-        if (use_pool && fe.kind == 3 && !fe.bf16 && (size_t)B * (size_t)e->a.S * 4 < (1ull << 31)) {
+        if (use_pool && fe.kind == 3 && !fe.bf16 && e->a.space == azd::SPACE_C21 && (size_t)B * (size_t)e->a.S * 4 < (1ull << 31)) {
             double wbytes = 0;
             for (int l = 0; l < fe.n_layers; ++l) wbytes += 4.0 * fe.dims[l] * fe.dims[l + 1];
             int force_g = 0;
@@ -1723,6 +1723,7 @@ static int roll_out_impl(azd_engine *e, const azd::TolTable &t, int n_calls, int
             sl.ctl = use_pool ? pool.ctl : nullptr;
             sl.hashed = fe.kind == 4;
             sl.window = ahead ? 1 : 0;
+            sl.groups = (use_pool && pool.grp_g > 0) ? 1 : 0;
             e->time_begin(0);
             if (use_pool) {
                 azd::launch_pool(e->a, e->d_pargs, sl, fe.params, fe.wpk, pool_blocks, dyn_stride, dyn_bytes, e->stream);

@@ -328,6 +328,7 @@ struct StepLaunch {
     const uint32_t *resume;
     PoolCtl *ctl;                  // pool step: the control block k_argmin_log1 reports the abort flag from and clears; else null
     int hashed;                    // pool step: FusedEval kind 4, the harness' instantiation of the kernel (k_pool<SP, 1>)
+    int groups = 0;                // pool step: PoolArgs::grp_g > 0 -- the instantiation with the evaluator groups (k_pool<SP, 4>; c21 space)
     int window;                    // pool step: publish every completed call to the host (PoolArgs::win_*)
 };
 

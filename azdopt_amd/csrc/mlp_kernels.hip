@@ -456,6 +456,8 @@ struct MlpEvaluator : azd_evaluator {
     float *d_split = nullptr;      // split-K parts of the largest weight gradient (gemm_dw)
     static constexpr int MAX_SPLITS = 64;
     float *d_wpk = nullptr;        // fragment-major weights for the asynchronous step (f32 words / bf16 halves)
+    float *d_part = nullptr;       // split-k partial sums of the bf16 forward (gemm_bf16_glds.inc)
+    size_t part_stride = 0;        // elements per slice
     std::vector<int64_t> p_off;
     int64_t n_packed = 0;
     bool fuse_hidden2 = true; // two consecutive 512-wide hidden layers in one launch (gemm_bf16_hidden2.inc; AZD_MLP_FUSE_HIDDEN=0: layer by layer)
@@ -467,7 +469,7 @@ struct MlpEvaluator : azd_evaluator {
         if (d_w16p) (void)hipFree(d_w16p);
         for (uint16_t *p : d_act16)
             if (p) (void)hipFree(p);
-        for (float *p : {d_params, d_grads, d_m, d_v, d_pred_train, d_delta_a, d_delta_b, d_partial, d_scalars, d_params_q, d_xq, d_wpk, d_split})
+        for (float *p : {d_params, d_grads, d_m, d_v, d_pred_train, d_delta_a, d_delta_b, d_partial, d_scalars, d_params_q, d_xq, d_wpk, d_split, d_part})
             if (p) (void)hipFree(p);
         for (float *p : d_act)
             if (p) (void)hipFree(p);
@@ -506,6 +508,12 @@ struct MlpEvaluator : azd_evaluator {
     }
 
     int alloc_act16() { // zeroed once: the kernels write columns < dims[l] only, the padding stays zero
+        if (d_part) (void)hipFree(d_part);
+        d_part = nullptr;
+        part_stride = 0;
+        for (int l = 0; l + 1 < L; ++l) // split-k layers (by shape: gemm16_ksplit): f32 partial sums, 8 slices at most, in batch row order
+            if (gemm16_ksplit(dims[(size_t)l + 1], kp[(size_t)l]) > 1 || getenv("AZD_GEMM16_KSPLIT")) part_stride = std::max(part_stride, (size_t)cap_batch * kp[(size_t)l + 1]);
+        if (part_stride) AZD_HIP(hipMalloc(&d_part, part_stride * 8 * sizeof(float)));
         for (uint16_t *&p : d_act16) {
             if (p) (void)hipFree(p);
             p = nullptr;
@@ -543,7 +551,8 @@ struct MlpEvaluator : azd_evaluator {
             }
             void *y = last ? (void *)d_p : (void *)(d_act16[(size_t)l + 1] + (size_t)act_row0 * kp[(size_t)l + 1]);
             launch_gemm16(st, x16, kp[(size_t)l], d_w16p + wp_off[(size_t)l], kp[(size_t)l], y, last ? dims[(size_t)L] : kp[(size_t)l + 1], batch,
-                          dims[(size_t)l + 1], kp[(size_t)l], last ? final_act : AZD_ACT_RELU, last ? 0 : 1, d_params + b_off[(size_t)l], n_cus);
+                          dims[(size_t)l + 1], kp[(size_t)l], last ? final_act : AZD_ACT_RELU, last ? 0 : 1, d_params + b_off[(size_t)l], n_cus, 0,
+                          (!last && d_part) ? d_part + (size_t)act_row0 * kp[(size_t)l + 1] : nullptr, part_stride);
             if (!last) x16 = d_act16[(size_t)l + 1] + (size_t)act_row0 * kp[(size_t)l + 1];
         }
         AZD_HIP(hipGetLastError());
@@ -641,7 +650,8 @@ struct MlpEvaluator : azd_evaluator {
             void *y = last ? (void *)d_p : (void *)(d_act16[(size_t)l + 1] + (size_t)act_row0 * kp[(size_t)l + 1]);
             launch_gemm16_ext(st, x16, kp[(size_t)l], d_w16p + wp_off[(size_t)l], kp[(size_t)l], y, last ? dims[(size_t)L] : kp[(size_t)l + 1], max_rows,
                               dims[(size_t)l + 1], kp[(size_t)l], last ? final_act : AZD_ACT_RELU, last ? 0 : 1, d_params + b_off[(size_t)l], n_cus, d_count,
-                              l == 0 ? d_rows : nullptr, last ? d_rows : nullptr);
+                              l == 0 ? d_rows : nullptr, last ? d_rows : nullptr,
+                              (!last && d_part) ? d_part + (size_t)act_row0 * kp[(size_t)l + 1] : nullptr, part_stride);
             if (!last) x16 = d_act16[(size_t)l + 1] + (size_t)act_row0 * kp[(size_t)l + 1];
         }
         AZD_HIP(hipGetLastError());

@@ -43,7 +43,7 @@ template <class SP>
 static void l_pool(const Arenas &a, const PersistArgs *d_args, const StepLaunch &sl, const float *params,
                    const void *wpk, int n_blocks, uint32_t dyn_stride, size_t dyn_bytes, hipStream_t st) {
     // the dynamic-LDS attribute is per device: set on every launch (see l_async)
-    const int mode = (sl.hashed ? 1 : 0) | (sl.window ? 2 : 0);
+    const int mode = (sl.hashed ? 1 : 0) | (sl.window ? 2 : 0) | ((sl.groups && !sl.hashed) ? 4 : 0);
 #define AZD_LAUNCH_POOL(M)                                                                                                          \
     case M:                                                                                                                         \
         if (hipFuncSetAttribute((const void *)k_pool<SP, M>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn_bytes) != hipSuccess) return; \
@@ -54,6 +54,8 @@ static void l_pool(const Arenas &a, const PersistArgs *d_args, const StepLaunch 
         AZD_LAUNCH_POOL(1)
         AZD_LAUNCH_POOL(2)
         AZD_LAUNCH_POOL(3)
+        AZD_LAUNCH_POOL(4) // evaluator groups (pool_eval_group) ...
+        AZD_LAUNCH_POOL(6) // ... and inside a run-ahead window
     }
 #undef AZD_LAUNCH_POOL
     k_argmin_log1<SP><<<dim3(1), dim3(64), SP::dyn_bytes(a), st>>>(a, sl.n_calls, sl.log_key, sl.ctl);
