@@ -12,7 +12,7 @@ _LIB = None
 
 CTR = dict(EXPANSIONS=0, TERMINALS=1, TRANSPOSITIONS=2, VISITED_STEPS=3, SELECT_CALLS=4, SUM_DEG=5,
            SUM_ACTIONS=6, CASCADE_NODES=7, NEW_PREDS=8, ROOT_EXHAUSTED=9, MAX_FRONTIER=10, MAX_DEPTH=11,
-           CURIOSITY_PAIRS=12, EVAL_LAYER_CLOCKS=13, FAILED=15, TICKS_TOTAL=16, TICKS_SELECT=17, TICKS_LOOKUP=18, TICKS_NEWNODE=19,
+           CURIOSITY_PAIRS=12, EVAL_LAYER_CLOCKS=13, TICKS_ADD_ACTIONS=14, FAILED=15, TICKS_TOTAL=16, TICKS_SELECT=17, TICKS_LOOKUP=18, TICKS_NEWNODE=19,
            TICKS_CASCADE=20, TICKS_MAX_CALL=21, TICKS_LAMBDA=22, TICKS_MATCHING=23, TICKS_WAIT=24, EVAL_BATCHES=25, EVAL_ROWS=26, EVAL_TILES=27, TICKS_TILES=28, TICKS_BATCH=29, TICKS_TILE_SETUP=30, TICKS_TILE_KLOOP=31)
 CTR_COUNT = 32
 

@@ -292,6 +292,7 @@ enum { /* indices into azd_engine_counters' output */
     AZD_CTR_CURIOSITY_PAIRS = 12,
     AZD_CTR_EVAL_LAYER_CLOCKS = 13, /* pool step: shader clocks the evaluator workgroups spent in the MLP's layers, summed (s_memtime); with
                                      * slot 31's 100 MHz ticks of the same spans it gives the clock the evaluator CUs actually held */
+    AZD_CTR_TICKS_ADD_ACTIONS = 14, /* pool step, AZD_WAVE_PHASES builds: ticks from an agent taken to its arrived row's actions added */
     AZD_CTR_FAILED_AGENTS = 15,
     /* 16..22: 100 MHz ticks per phase of the roll-out kernel, summed over agents; filled only by
      * the diagnostic build (make PROFILE=1), 0 otherwise */
