@@ -1,9 +1,9 @@
 #!/bin/bash
 # Profile refresh of a round (run on the GPU box through gpurun; tools/update_profiles.py copies the summaries to profiles/):
-#   tools/refresh_profiles.sh r04 [part ...]     parts: bench stats tcc tcc20 l2 sq gemm split curve examples  (default: all)
+#   tools/refresh_profiles.sh r05 [part ...]     parts: bench stats tcc tcc20 l2 sq insts phases gemm split curve examples  (default: all)
 export TMPDIR=/tmp
 R=${1:-r05}; shift
-PARTS=${*:-bench stats tcc tcc20 l2 sq insts gemm split curve examples}
+PARTS=${*:-bench stats tcc tcc20 l2 sq insts phases gemm split curve examples}
 O=gpurun_out/final_$R
 mkdir -p $O
 has() { [[ " $PARTS " == *" $1 "* ]]; }
@@ -53,6 +53,11 @@ if has insts; then  # the instruction table (profiles/<round>_pool_insts.txt): p
       timeout -k 10 200 rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_SMEM SQ_WAVES SQ_INSTS_VALU_MFMA_MOPS_F32 --kernel-trace --output-format csv -d $O/pmc_i_$form -- python3 tools/inst_run.py $form 4096 $n 2>/dev/null | grep -E "^form|^EXPANSIONS"
       python tools/pmc_kernels.py $O/pmc_i_$form | grep -E "k_pool|k_rollout|k_add_actions|k_gemm|k_argmin" ; rm -rf $O/pmc_i_$form; done; } > $O/insts.txt 2>&1
   echo insts done
+fi
+if has phases; then  # a searcher wave's time by phase at the product build's rate (AZD_WAVE_PHASES build) and the driver's window by agent (PROFILE build)
+  { for cfg in "4096 800 f32" "8192 800 bf16" "8192 800 f32"; do AZD_LIB=azdopt_amd/libazdopt_amd_phases.so timeout -k 10 200 python tools/wave_phases.py $cfg; done; } > $O/wave_phases.txt 2>&1
+  AZD_LIB=azdopt_amd/libazdopt_amd_prof.so timeout -k 10 200 python tools/window_tail.py 4096 20 390 > $O/window_tail.txt 2>&1
+  echo phases done
 fi
 if has gemm; then
   { timeout -k 10 200 python tools/time_gemm16.py; echo "# zero-filled operands (they read higher; for comparison with figures quoted that way):"; AZD_GEMM_ZEROS=1 timeout -k 10 200 python tools/time_gemm16.py 8192 4096 4096; for dt in bf16 f32; do timeout -k 10 100 python tools/time_gemm.py $dt 8192; timeout -k 10 100 python tools/time_gemm.py $dt 65536 304,256,256,256,152; timeout -k 10 100 python tools/time_gemm.py $dt 8192 4096,4096,4096; done; AZD_GEMM_OLD=1 timeout -k 10 100 python tools/time_gemm.py bf16 8192;

@@ -174,6 +174,17 @@ if sq2:
              "wave_insts_per_call": {k.replace("SQ_INSTS_", "").lower(): v / calls for k, v in sorted(tot.items()) if k.startswith("SQ_INSTS_")}}
     json.dump(issue, open(os.path.join(P, "issue.json"), "w"), indent=1)
     print("k_pool wave-instructions per call:", {k: round(v) for k, v in issue["wave_insts_per_call"].items()})
+    # how to divide the sums above: they cover EVERY k_pool dispatch of the profiled command (warm-up epoch + timed epoch), not the timed one
+    lg = os.path.join(O, "pmc_sq2.log")
+    bl = [x for x in open(lg).read().splitlines() if x.startswith('{"metric')] if os.path.exists(lg) else []
+    with open(os.path.join(P, R + "_pool_pmc_sq.txt"), "a") as f:
+        f.write("# The sums cover %d dispatches of k_pool = %d calls of 4096 agents (the profiled command's warm-up epoch AND its timed epoch).\n" % (len(disp), calls))
+        if bl:
+            d = json.loads(bl[-1])
+            epc = d["expansions"] / d["steps"]
+            f.write("# Expansions per call in the timed epoch of that run: %.0f  ->  wave-instructions per expansion: " % epc)
+            f.write(", ".join("%s %.0f" % (k.replace("SQ_INSTS_", ""), v / calls / epc) for k, v in sorted(tot.items()) if k.startswith("SQ_INSTS_") and "MFMA" not in k and k != "SQ_WAVES"))
+            f.write(" (MFMA ops are counted inside VALU; profiles/issue.json holds the per-call figures bench.py's roofline_issue block uses)\n")
 m = [x for x in open(os.path.join(O, "prof.log")).read().splitlines() if x.startswith('{"metric')] if os.path.exists(os.path.join(O, "prof.log")) else []
 if m:
     print("bench HIP-event avg in the profiled run:", json.loads(m[-1])["roofline"]["avg_launch_ms"])
