@@ -119,3 +119,25 @@ def test_fused_hidden_layers_equal_the_layer_by_layer_forward(az, monkeypatch, B
         ys.append(y)
     assert np.array_equal(ys[0].view(np.uint32), ys[1].view(np.uint32))
     assert np.max(np.abs(ys[0] - reference_forward(m.get_params(), dims, x))) < BF16_ATOL
+
+
+@pytest.mark.parametrize("slices,form", [("4", None), ("2", "128"), ("8", "1064")])
+def test_experiment_knobs_of_the_long_k_gemm_keep_the_forward_within_tolerance(az, monkeypatch, slices, form):
+    """AZD_GEMM16_KSPLIT (the first layer's k loop dealt to 2 / 4 / 8 blocks per tile, partial sums added in slice order) and
+    AZD_GEMM16_LONGK_FORM (another tile form): measured and left off -- but a knob that is documented runs:
+    the forward stays within the bf16 mode's tolerance of the restatement, and two runs of the split give the same bits (the
+    slices are added in a fixed order, whichever block finishes first)."""
+    dims, B = (3676, 512, 512, 512, 2450), 200
+    rng = np.random.default_rng(9)
+    x = rng.integers(0, 3, (B, dims[0])).astype(F) * (rng.random((B, dims[0])) < 0.3)
+    monkeypatch.setenv("AZD_GEMM16_KSPLIT", slices)
+    if form:
+        monkeypatch.setenv("AZD_GEMM16_LONGK_FORM", form)
+    m = az.ActionModel(B, dims[0], dims[-1], hidden=dims[1:-1], seed=11, dtype="bf16")
+    ys = []
+    for _ in range(2):
+        y = np.zeros((B, dims[-1]), F)
+        m.write_predictions(x, y)
+        ys.append(y)
+    assert np.array_equal(ys[0].view(np.uint32), ys[1].view(np.uint32))
+    assert np.max(np.abs(ys[0] - reference_forward(m.get_params(), dims, x))) < BF16_ATOL
