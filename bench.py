@@ -501,6 +501,18 @@ def main():
                                   % (kernel, cpl)
             except Exception:
                 traffic = None
+        elif os.path.exists(tpath) and getattr(args, "config", None):
+            # the other BASELINE configurations: the committed profile of THIS configuration's dominant kernel at its default population
+            # (tools/refresh_profiles.sh tccx: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE over bench.py --config X), per call x this run's calls
+            try:
+                e = json.load(open(tpath)).get("by_config", {}).get(args.config)
+                if e and e["kernel"] == kernel and e["step_form"] == form and e["agents_per_gpu"] == AGENTS_PER_GPU and e["dtype"] == mlp_dtype:
+                    cpl = args.steps / launches
+                    traffic = e["hbm_bytes_per_call"] * cpl
+                    traffic_src = "profiles/traffic.json by_config[%s] (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE of %s in separate passes over bench.py --config %s, " \
+                                  "round %s) x %.0f calls per launch; not measured in this run" % (args.config, kernel, args.config, e.get("round", "?"), cpl)
+            except Exception:
+                traffic = None
         # the limiter the kernel actually runs into: a call is a CHAIN of dependent gathers (a node's predictions, then its
         # children's records, per selection step; table probes; cascade records), one round trip each for the wave that runs
         # it.  Bound: resident searching waves / (dependent round trips per call x the idle HBM-miss latency of

@@ -1,9 +1,9 @@
 #!/bin/bash
 # Profile refresh of a round (run on the GPU box through gpurun; tools/update_profiles.py copies the summaries to profiles/):
-#   tools/refresh_profiles.sh r05 [part ...]     parts: bench stats tcc tcc20 l2 sq insts phases gemm split curve examples  (default: all)
+#   tools/refresh_profiles.sh r05 [part ...]     parts: bench stats tcc tcc20 tccx l2 sq insts phases gemm split curve examples  (default: all)
 export TMPDIR=/tmp
 R=${1:-r05}; shift
-PARTS=${*:-bench stats tcc tcc20 l2 sq insts phases gemm split curve examples}
+PARTS=${*:-bench stats tcc tcc20 tccx l2 sq insts phases gemm split curve examples}
 O=gpurun_out/final_$R
 mkdir -p $O
 has() { [[ " $PARTS " == *" $1 "* ]]; }
@@ -36,6 +36,13 @@ if has tcc20; then  # the same two counters over the DRIVER's window: launches o
   timeout -k 10 300 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $O/pmc_fetch20 -- python3 bench.py --no-cpu-baseline --steps 20 --warmup 5 > $O/pmc_fetch20.log 2>&1
   timeout -k 10 300 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $O/pmc_write20 -- python3 bench.py --no-cpu-baseline --steps 20 --warmup 5 > $O/pmc_write20.log 2>&1
   echo tcc20 done
+fi
+if has tccx; then  # the same two counters for the other BASELINE configurations' dominant kernels (bench.py --config A / C / D / E: whole epochs)
+  for cfg in A C D E; do
+    timeout -k 10 400 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $O/pmc_fetch_$cfg -- python3 bench.py --no-cpu-baseline --config $cfg > $O/pmc_fetch_$cfg.log 2>&1
+    timeout -k 10 400 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $O/pmc_write_$cfg -- python3 bench.py --no-cpu-baseline --config $cfg > $O/pmc_write_$cfg.log 2>&1
+  done
+  echo tccx done
 fi
 if has l2; then  # where the tree's records are served from: L2 hits / misses of k_pool (all XCDs summed), one pass
   timeout -k 10 300 rocprofv3 --pmc TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum --kernel-trace --output-format csv -d $O/pmc_l2 -- python3 bench.py --no-cpu-baseline --steps 800 --warmup 800 > $O/pmc_l2.log 2>&1

@@ -104,6 +104,38 @@ if f20 and w20:
     engine_rows(w20, os.path.join(P, R + "_pool_driver20_pmc_write_size.csv"))
     print("k_pool traffic per call in the driver's 20-call launch: %.1f MB (FETCH %.1f + WRITE %.1f)" % (
         (f_last + w_last) * 1024 / 20 / 1e6, f_last * 1024 / 20 / 1e6, w_last * 1024 / 20 / 1e6))
+# the other configurations' dominant kernels (part tccx): per-call traffic into traffic.json["by_config"]
+for cfg, needle in (("A", "k_pool<"), ("C", "k_pool<"), ("D", "k_pool<"), ("E", "k_pool_search<")):
+    fx, wx = newest("pmc_fetch_%s/**/*counter_collection.csv" % cfg), newest("pmc_write_%s/**/*counter_collection.csv" % cfg)
+    lg = os.path.join(O, "pmc_fetch_%s.log" % cfg)
+    if not (fx and wx and os.path.exists(lg)):
+        continue
+    bl = [x for x in open(lg).read().splitlines() if x.startswith('{"metric')]
+    if not bl:
+        continue
+    d = json.loads(bl[-1])
+    fetch, n1 = total(fx, "FETCH_SIZE", needle)
+    write, n2 = total(wx, "WRITE_SIZE", needle)
+    if n1 == 0 or n1 != n2:
+        print("tccx %s: dispatch counts differ (%d / %d): skipped" % (cfg, n1, n2))
+        continue
+    cpl = d.get("calls_per_launch") or 800.0
+    calls = cpl * n1
+    t = json.load(open(os.path.join(P, "traffic.json")))
+    t.setdefault("by_config", {})[cfg] = {
+        "kernel": d["roofline"]["kernel"], "step_form": d["step_form"], "agents_per_gpu": d["config"]["agents_total"], "dtype": d["dtype"],
+        "dispatches": n1, "calls_per_launch": cpl, "FETCH_SIZE_KB_total": fetch, "WRITE_SIZE_KB_total": write,
+        "hbm_bytes_per_call": (fetch + write) * 1024 / calls,
+        "algorithmic_bytes_per_call": d["roofline"]["algorithmic_bytes_per_expansion"] * d["expansions"] / d["steps"],
+        "commands": ["rocprofv3 --pmc %s --kernel-trace --output-format csv -d gpurun_out/final_%s/pmc_%s_%s -- python3 bench.py --no-cpu-baseline --config %s" % (c, R, c.split("_")[0].lower(), cfg, cfg)
+                     for c in ("FETCH_SIZE", "WRITE_SIZE")], "round": R}
+    json.dump(t, open(os.path.join(P, "traffic.json"), "w"), indent=1)
+    engine_rows(fx, os.path.join(P, "%s_config%s_pmc_fetch_size.csv" % (R, cfg)))
+    engine_rows(wx, os.path.join(P, "%s_config%s_pmc_write_size.csv" % (R, cfg)))
+    e = t["by_config"][cfg]
+    print("config %s %s traffic per call: %.1f MB (FETCH %.1f + WRITE %.1f) against %.1f MB algorithmic = %.2f x" % (
+        cfg, e["kernel"], e["hbm_bytes_per_call"] / 1e6, fetch * 1024 / calls / 1e6, write * 1024 / calls / 1e6, e["algorithmic_bytes_per_call"] / 1e6,
+        e["hbm_bytes_per_call"] / e["algorithmic_bytes_per_call"]))
 l2 = newest("pmc_l2/**/*counter_collection.csv")
 if l2:
     tot = {}
