@@ -1508,6 +1508,16 @@ static int roll_out_impl(azd_engine *e, const azd::TolTable &t, int n_calls, int
                 n_eval = n_eval > most ? most : n_eval;
                 n_eval = n_eval < 1 ? 1 : n_eval;
             }
+            // a SHORT launch is fill and drain (its length is its slowest agents' few calls, each with an evaluator round trip in it): a seventh
+            // more evaluator workgroups than the busy shares of whole epochs ask for -- bench.py --steps 20, 4096 agents, same box, four
+            // alternating runs each: 104 workgroups 27.7 / 28.6 / 30.1 / 29.4 M expansions/s, 116: 29.9 / 29.2 / 29.3 / 29.8, 124: 29.5 / 29.8 /
+            // 29.6 / 29.6 (round 5; the launch over its median agent 1.50 -> 1.44 -> 1.37)
+            if (n_calls <= 64 && fe.kind == 3) {
+                const int want_search = (B + 7) / 8, most = want_search < e->n_cus / 2 ? e->n_cus - want_search : e->n_cus / 2;
+                n_eval += n_eval / 7;
+                n_eval = n_eval > most ? most : n_eval;
+                n_eval = n_eval > cap ? cap : n_eval;
+            }
             if (const char *env = getenv("AZD_POOL_EVAL_WGS")) n_eval = atoi(env) > 0 ? atoi(env) : n_eval;
         }
         int n_search = e->n_cus - n_eval;
