@@ -8,7 +8,8 @@ from collections import defaultdict
 
 root, needle = sys.argv[1], sys.argv[2]
 tot = defaultdict(float)
-for f in glob.glob(os.path.join(root, "**", "*counter_collection.csv"), recursive=True):
+files = sorted(glob.glob(os.path.join(root, "**", "*counter_collection.csv"), recursive=True), key=os.path.getmtime)
+for f in files[-1:]:  # the newest run only (gpurun merges a re-run's files into the same directory: summing them all doubled the counts)
     for row in csv.DictReader(open(f)):
         if needle in row["Kernel_Name"]:
             tot[row["Counter_Name"]] += float(row["Counter_Value"])
