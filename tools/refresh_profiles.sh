@@ -38,7 +38,7 @@ if has tcc20; then  # the same two counters over the DRIVER's window: launches o
   echo tcc20 done
 fi
 if has tccx; then  # the same two counters for the other BASELINE configurations' dominant kernels (bench.py --config A / C / D / E: whole epochs)
-  for cfg in A C D E; do
+  for cfg in A C D; do  # (E: the counter mode serialises dispatches; the dense pool step is two concurrent kernels)
     timeout -k 10 400 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $O/pmc_fetch_$cfg -- python3 bench.py --no-cpu-baseline --config $cfg > $O/pmc_fetch_$cfg.log 2>&1
     timeout -k 10 400 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $O/pmc_write_$cfg -- python3 bench.py --no-cpu-baseline --config $cfg > $O/pmc_write_$cfg.log 2>&1
   done
