@@ -231,3 +231,39 @@ def test_a_sweep_never_meets_an_already_inactive_ancestor():
     finally:
         po.PyTree.cascade = orig
     assert hits["visits"] > 2000 and hits["merges"] > 100 and hits["inactive_before"] == 0, hits
+
+
+def test_the_c21_spaces_actions_commute_which_the_device_builds_states_on():
+    """The device no longer applies a descent's actions one by one: a new node's state is root + {the path's action set}, applied at
+    once (C21Space::act_set).  That is the reference's state only because the space's actions commute and never repeat
+    (ActionOrderIndependent + ActionsNeverRepeat, rooted_tree/space.rs:124-125; space/axioms.rs:16-19).  Checked here on the Python
+    restatement of `act` (space.rs:56-73): every legal sequence from seeded roots, taken step by step, ends on the state that ANY
+    order of its action set gives, and no action of a path is legal again further down it."""
+    import random
+
+    from oracle import py_oracle as po
+
+    rng = random.Random(5)
+    for n in (8, 13, 19):
+        S, A = po.dims(n)
+        for agent in range(40):
+            parents, permitted = po.fresh_root(1, 0, agent, n, rng.randint(5, A // 2))
+            parents, permitted = list(parents), set(permitted)
+            p0, m0 = list(parents), set(permitted)
+            taken = []
+            while True:
+                legal = po.legal_actions(n, parents, permitted)
+                if not legal or len(taken) >= 16:
+                    break
+                a = rng.choice(legal)
+                assert a not in taken
+                po.act(parents, permitted, a)
+                taken.append(a)
+                assert a not in po.legal_actions(n, parents, permitted)
+            for _ in range(4):
+                order = taken[:]
+                rng.shuffle(order)
+                p1, m1 = list(p0), set(m0)
+                for a in order:
+                    po.act(p1, m1, a)
+                assert p1 == parents and m1 == permitted, (n, agent, taken, order)
