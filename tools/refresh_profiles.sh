@@ -7,6 +7,14 @@ PARTS=${*:-bench stats tcc tcc20 tccx l2 sq insts phases gemm split curve exampl
 O=gpurun_out/final_$R
 mkdir -p $O
 has() { [[ " $PARTS " == *" $1 "* ]]; }
+# the diagnostic libraries of the insts / phases parts are built on the build machine and travel with the snapshot:
+#   make -C azdopt_amd/csrc -j8 PROFILE=1                                        -> azdopt_amd/libazdopt_amd_prof.so
+#   make -C azdopt_amd/csrc -j8 VARIANT=phases EXTRA=-DAZD_WAVE_PHASES=1         -> azdopt_amd/libazdopt_amd_phases.so
+for part in insts phases; do
+  if has $part && { [ ! -f azdopt_amd/libazdopt_amd_prof.so ] || { [ $part = phases ] && [ ! -f azdopt_amd/libazdopt_amd_phases.so ]; }; }; then
+    echo "refresh_profiles: part '$part' needs the diagnostic libraries (see the head of this script): skipped"; PARTS=${PARTS//$part/}
+  fi
+done
 if has bench; then
   timeout -k 10 300 python bench.py > $O/bench_default.log 2>&1; tail -1 $O/bench_default.log | cut -c1-140
   timeout -k 10 200 python bench.py --steps 20 --warmup 5 --no-cpu-baseline > $O/bench_driver20.log 2>&1
